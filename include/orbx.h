@@ -1,0 +1,188 @@
+/*
+ * orbx - MI355X (gfx950) ORB feature front-end, C ABI.
+ *
+ * This header is the whole drop-in boundary: plain C types, no C++ exceptions,
+ * no torch types.  Every function returns an orbx_status (0 = ok, negative =
+ * error) unless stated otherwise.  Each entry point names the reference
+ * interface (paths relative to the ORB-SLAM3 tree) whose work it performs.
+ *
+ * Threading: one orbx_extractor owns one HIP stream and private device
+ * buffers.  Different extractors may be used concurrently from different host
+ * threads (the reference runs one extractor per camera on its own thread,
+ * core/src/Frame.cc:151-154); a single extractor must not be called
+ * concurrently with itself.
+ */
+#ifndef ORBX_H_
+#define ORBX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum orbx_status {
+  ORBX_OK = 0,
+  ORBX_ERR_EMPTY_IMAGE = -1,  /* reference returns -1, core/lib/ORB/extractor.cc:1023-1024 */
+  ORBX_ERR_TOO_SMALL = -2,    /* a pyramid level has no 35-px cell (reference: undefined) */
+  ORBX_ERR_CAPACITY = -3,     /* output capacity too small; *n_out holds the need */
+  ORBX_ERR_BAD_ARG = -4,
+  ORBX_ERR_NO_DEVICE = -5,    /* no usable HIP device / HIP runtime error at set-up */
+  ORBX_ERR_HIP = -6,          /* HIP runtime error during a call */
+  ORBX_ERR_UNSUPPORTED = -7,  /* parameters beyond what the kernels are sized for */
+  ORBX_ERR_BATCH = -8         /* more frames than the handle's max_batch */
+} orbx_status;
+
+/* cv::KeyPoint layout (28 bytes): pt.x, pt.y, size, angle, response, octave, class_id. */
+typedef struct orbx_keypoint {
+  float x, y, size, angle, response;
+  int32_t octave, class_id;
+} orbx_keypoint;
+
+/* Constructor arguments of ORB_SLAM3::ORBextractor (core/lib/ORB/extractor.h:49-50)
+ * plus where to run. */
+typedef struct orbx_params {
+  int32_t nfeatures;
+  float scale_factor;
+  int32_t nlevels;
+  int32_t ini_th_fast;
+  int32_t min_th_fast;
+  int32_t device_id; /* HIP device ordinal */
+  int32_t max_batch; /* frames per batched call this handle is sized for, >= 1 */
+} orbx_params;
+
+typedef struct orbx_extractor orbx_extractor;
+
+const char* orbx_strerror(int status);
+
+/* ORBextractor::ORBextractor, core/lib/ORB/extractor.cc:406-463. */
+int orbx_create(const orbx_params* params, orbx_extractor** out);
+void orbx_destroy(orbx_extractor* ex);
+
+/* GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares /
+ * GetInverseScaleSigmaSquares (extractor.h:61-73) and mnFeaturesPerLevel.
+ * Each array holds nlevels entries; any pointer may be NULL. */
+int orbx_get_tables(const orbx_extractor* ex, float* scale, float* inv_scale, float* sigma2,
+                    float* inv_sigma2, int32_t* features_per_level);
+
+/* Upper bound on the number of keypoints one frame can produce with this
+ * handle (the quadtree may exceed nfeatures, extractor.cc:595-723). */
+int orbx_max_keypoints(const orbx_extractor* ex);
+
+/* ORBextractor::operator(), core/lib/ORB/extractor.cc:1018-1101.
+ * Host image in (8-bit, row stride in bytes), host keypoints/descriptors out.
+ * kps and desc hold cap entries (cap*28 and cap*32 bytes).  *n_out = number
+ * of keypoints, *mono_out = the reference's return value (monoIndex): entries
+ * [0, mono) lie outside [lap0, lap1] in x, entries [mono, n) inside, the
+ * latter filled back to front.  Blocks until the outputs are on the host. */
+int orbx_extract(orbx_extractor* ex, const uint8_t* img, int width, int height, int stride,
+                 int lap0, int lap1, orbx_keypoint* kps, uint8_t* desc, int cap, int* n_out,
+                 int* mono_out);
+
+/* mvImagePyramid of the last orbx_extract call (extractor.h:75,
+ * extractor.cc:1103-1127): host pointer to the padded level (19-pixel
+ * REFLECT_101 border on every side); the level image starts at
+ * padded + 19*stride + 19.  Downloaded lazily; valid until the next call on
+ * this handle. */
+int orbx_pyramid(orbx_extractor* ex, int level, const uint8_t** padded, int* width, int* height,
+                 int* stride);
+
+/* Batched operator(): n_frames equally sized host images -> per-frame outputs.
+ * kps/desc hold n_frames*cap entries, frame f at offset f*cap. */
+int orbx_extract_batch(orbx_extractor* ex, int n_frames, const uint8_t* const* imgs, int width,
+                       int height, int stride, int lap0, int lap1, orbx_keypoint* kps,
+                       uint8_t* desc, int cap, int* n_out, int* mono_out);
+
+/* Device-resident batched operator(): d_imgs points at n_frames contiguous
+ * images (height*stride bytes each) in device memory.  Work is enqueued on the
+ * handle's stream and the call returns without waiting; results stay in the
+ * handle's device buffers (orbx_batch_results_device) until the next call.
+ * orbx_sync waits for completion. */
+int orbx_extract_batch_device(orbx_extractor* ex, int n_frames, const uint8_t* d_imgs, int width,
+                              int height, int stride, int lap0, int lap1);
+int orbx_sync(orbx_extractor* ex);
+
+/* Device buffers of the last batched call: keypoints [n_frames][cap] (28 B),
+ * descriptors [n_frames][cap][32], n and mono as int32[n_frames]. */
+int orbx_batch_results_device(orbx_extractor* ex, orbx_keypoint** d_kps, uint8_t** d_desc,
+                              int32_t** d_n, int32_t** d_mono, int* cap);
+/* Copy frame f of the last batched call to the host. */
+int orbx_batch_download(orbx_extractor* ex, int frame, orbx_keypoint* kps, uint8_t* desc, int cap,
+                        int* n_out, int* mono_out);
+
+/* The handle's HIP stream (hipStream_t as void*), for callers that order
+ * their own work against it. */
+void* orbx_stream(orbx_extractor* ex);
+
+/* ---- stage dumps (parity tests; frame indexes the last batched call) ------ */
+/* Padded pyramid level of one frame into dst (rows*stride bytes, stride from
+ * orbx_level_dims). */
+int orbx_level_dims(orbx_extractor* ex, int level, int* width, int* height, int* stride);
+int orbx_debug_level_padded(orbx_extractor* ex, int frame, int level, uint8_t* dst);
+/* FAST candidates of one level in quadtree input order: (x, y, score) triples,
+ * coordinates relative to (16,16) as in extractor.cc:822-829. */
+int orbx_debug_level_candidates(orbx_extractor* ex, int frame, int level, int32_t* xys, int cap,
+                                int* n_out);
+/* Quadtree-selected keys of one level, in list order, same triples. */
+int orbx_debug_level_selected(orbx_extractor* ex, int frame, int level, int32_t* xys, int cap,
+                              int* n_out);
+/* Blurred level image (width*height bytes, contiguous). */
+int orbx_debug_level_blurred(orbx_extractor* ex, int frame, int level, uint8_t* dst);
+
+/* ---- timing --------------------------------------------------------------- */
+#define ORBX_STAGE_PYRAMID 0
+#define ORBX_STAGE_FAST 1
+#define ORBX_STAGE_OCTREE 2
+#define ORBX_STAGE_ASSEMBLE 3
+#define ORBX_STAGE_BLUR 4
+#define ORBX_STAGE_DESCRIBE 5
+#define ORBX_NUM_STAGES 6
+/* When enabled, HIP events on the handle's stream bracket every stage of a
+ * batched call; orbx_stage_times (after orbx_sync) returns the milliseconds
+ * of the last call per stage. */
+int orbx_set_profiling(orbx_extractor* ex, int enabled);
+int orbx_stage_times(orbx_extractor* ex, float* ms, int n);
+
+/* ---- Hamming matching ------------------------------------------------------ */
+/* ORBmatcher::DescriptorDistance, core/lib/ORB/matcher.cc:1961-1975 (host). */
+int orbx_hamming(const uint8_t* a, const uint8_t* b);
+
+/* Brute-force Hamming 2-NN: what cv::BFMatcher(NORM_HAMMING).knnMatch(q, t, m, 2)
+ * returns at core/src/Frame.cc:1177: per query the two nearest train rows by
+ * (distance, train index) ascending.  idx holds nq*2 uint32, dist nq*2
+ * uint16; missing neighbours (nt < 2) are idx 0xFFFFFFFF / dist 0xFFFF.
+ * Host pointers; runs on device_id. */
+int orbx_knn2(int device_id, const uint8_t* q, int nq, const uint8_t* t, int64_t nt,
+              uint32_t* idx, uint16_t* dist);
+/* Same on device pointers, asynchronous on stream (hipStream_t as void*, NULL
+ * = default stream).  Train row j is reported as index j + index_offset, so a
+ * database shard reports global indices. */
+int orbx_knn2_device(const uint8_t* d_q, int nq, const uint8_t* d_t, int64_t nt,
+                     uint32_t index_offset, uint32_t* d_idx, uint16_t* d_dist, void* stream);
+/* Merge nparts partial 2-NN results (layout [part][nq][2]) into the global
+ * 2-NN with the same (distance, index) ordering.  Device pointers. */
+int orbx_top2_merge_device(const uint32_t* d_idx_parts, const uint16_t* d_dist_parts, int nparts,
+                           int nq, uint32_t* d_idx, uint16_t* d_dist, void* stream);
+
+/* Row-band stereo descriptor search: the first half of
+ * Frame::ComputeStereoMatches, core/src/Frame.cc:840-908.  For each left
+ * keypoint the right keypoint with the smallest Hamming distance among those
+ * whose row band contains the left row, whose octave differs by at most one
+ * and whose x lies in [uL - max_d, uL - min_d]; best_dist starts at 100 and
+ * the first candidate in ascending right index wins ties.  best_idx = -1 and
+ * best_dist = 100 when nothing qualified.  Host pointers; runs on device_id. */
+int orbx_stereo_band_match(int device_id, const orbx_keypoint* kps_l, const uint8_t* desc_l,
+                           int n_l, const orbx_keypoint* kps_r, const uint8_t* desc_r, int n_r,
+                           const float* scale_factors, int nlevels, int n_rows, float min_d,
+                           float max_d, int32_t* best_idx, int32_t* best_dist);
+
+/* ---- synthetic input ------------------------------------------------------- */
+/* Deterministic textured test frame (PCG32-seeded rectangles + noise + 3x3
+ * box blur), written to dst (height rows of stride bytes).  Host only. */
+int orbx_synth_frame(uint32_t seed, int width, int height, int stride, uint8_t* dst);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBX_H_ */

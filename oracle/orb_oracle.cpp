@@ -1,0 +1,800 @@
+// CPU ORACLE for the ORB front-end.  TEST INFRASTRUCTURE ONLY.
+//
+// This file restates, on the CPU and with no dependencies, the algorithm of
+// the reference's ORB extractor and Hamming matchers.  It exists to check the
+// HIP implementation and to serve as the timed CPU baseline; the product
+// (liborbx_hip.so and the orb_slam3_amd package) never calls it.
+//
+// PARITY STATUS: "parity unpinned".  The reference ships no tests, golden
+// vectors or fixtures for this path, and its arithmetic lives in OpenCV
+// (>= 4.4, unpinned; core/CMakeLists.txt:14), which is absent here, so the
+// reference itself cannot be built.  The OpenCV primitives it calls
+// (resize INTER_LINEAR 8U, copyMakeBorder REFLECT_101, FAST 9/16 with NMS,
+// GaussianBlur 7x7 sigma 2 fixed-point, fastAtan2, cvRound) are restated from
+// OpenCV 4.x's published algorithms.  What pins this file: the in-tree data
+// (BRIEF pattern, constants), the derived known answers (per-level quotas,
+// umax, level sizes, blur kernel) and self-consistency tests under tests/.
+//
+// Floating-point canon (build with -ffp-contract=off):
+//   * no fused multiply-add anywhere;
+//   * cos/sin of the keypoint angle = float(cos(double(angle_rad))).
+//
+// Each function cites the reference lines (relative to /root/reference) it
+// follows.
+#include <algorithm>
+#include <cfloat>
+#include <climits>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <list>
+#include <utility>
+#include <vector>
+
+namespace {
+
+const int kPatch = 31;       // core/lib/ORB/extractor.cc:71
+const int kHalfPatch = 15;   // :72
+const int kEdge = 19;        // :73
+const int kCellW = 35;       // :751
+
+const int kPattern[256 * 4] = {
+#include "orb_pattern_31.inc"
+};
+
+struct KeyPoint {  // cv::KeyPoint layout, 28 bytes
+  float x, y, size, angle, response;
+  int octave, class_id;
+};
+
+// ---- OpenCV scalar helpers -------------------------------------------------
+// cvRound: round half to even (SSE cvtss2si / lrint under the default mode).
+inline int cvRoundF(float v) { return (int)lrintf(v); }
+inline int cvRoundD(double v) { return (int)lrint(v); }
+inline int cvFloorF(float v) {
+  int i = (int)v;
+  return i - (i > v);
+}
+inline int cvCeilF(float v) {
+  int i = (int)v;
+  return i + (i < v);
+}
+inline short satShort(float v) {
+  int r = cvRoundF(v);
+  return (short)std::min(std::max(r, -32768), 32767);
+}
+// BORDER_REFLECT_101 index map: gfedcb|abcdefgh|gfedcba
+inline int reflect101(int i, int n) {
+  if (n == 1) return 0;
+  while (i < 0 || i >= n) {
+    if (i < 0) i = -i;
+    else i = 2 * n - 2 - i;
+  }
+  return i;
+}
+
+// cv::fastAtan2 (degrees, polynomial approximation).
+float fastAtan2(float y, float x) {
+  const float k = (float)(180.0 / 3.1415926535897932384626433832795);
+  const float p1 = 0.9997878412794807f * k;
+  const float p3 = -0.3258083974640975f * k;
+  const float p5 = 0.1555786518463281f * k;
+  const float p7 = -0.04432655554792128f * k;
+  float ax = std::fabs(x), ay = std::fabs(y);
+  float a, c, c2;
+  if (ax >= ay) {
+    c = ay / (ax + (float)DBL_EPSILON);
+    c2 = c * c;
+    a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  } else {
+    c = ax / (ay + (float)DBL_EPSILON);
+    c2 = c * c;
+    a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  }
+  if (x < 0) a = 180.f - a;
+  if (y < 0) a = 360.f - a;
+  return a;
+}
+
+// ---- image container -------------------------------------------------------
+struct Plane {  // padded level: data holds (h+2*kEdge) rows of stride bytes
+  int w = 0, h = 0, stride = 0;
+  std::vector<uint8_t> data;
+  uint8_t* roi() { return data.data() + kEdge * stride + kEdge; }
+  const uint8_t* roi() const { return data.data() + kEdge * stride + kEdge; }
+};
+
+// cv::resize(src, dst, dsize, 0, 0, INTER_LINEAR) for CV_8UC1: fixed-point
+// bilinear with 11-bit coefficients, horizontal pass to int32, vertical pass
+// with the 8-bit specialisation's double shift.
+void resizeLinearU8(const uint8_t* src, int sw, int sh, int sstride,
+                    uint8_t* dst, int dw, int dh, int dstride) {
+  const double scale_x = 1.0 / ((double)dw / sw);
+  const double scale_y = 1.0 / ((double)dh / sh);
+  std::vector<int> xofs(dw), yofs(dh);
+  std::vector<short> alpha(2 * dw), beta(2 * dh);
+  for (int dx = 0; dx < dw; ++dx) {
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = cvFloorF(fx);
+    fx -= sx;
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+    xofs[dx] = sx;
+    alpha[2 * dx] = satShort((1.f - fx) * 2048);
+    alpha[2 * dx + 1] = satShort(fx * 2048);
+  }
+  for (int dy = 0; dy < dh; ++dy) {
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    int sy = cvFloorF(fy);
+    fy -= sy;
+    yofs[dy] = sy;
+    beta[2 * dy] = satShort((1.f - fy) * 2048);
+    beta[2 * dy + 1] = satShort(fy * 2048);
+  }
+  std::vector<int> row0(dw), row1(dw);
+  auto hpass = [&](int sy, std::vector<int>& out) {
+    sy = std::min(std::max(sy, 0), sh - 1);
+    const uint8_t* S = src + (size_t)sy * sstride;
+    for (int dx = 0; dx < dw; ++dx) {
+      int sx = xofs[dx];
+      if (sx + 1 >= sw) out[dx] = S[sx] * 2048;  // single tap past xmax
+      else out[dx] = S[sx] * alpha[2 * dx] + S[sx + 1] * alpha[2 * dx + 1];
+    }
+  };
+  for (int dy = 0; dy < dh; ++dy) {
+    hpass(yofs[dy], row0);
+    hpass(yofs[dy] + 1, row1);
+    int b0 = beta[2 * dy], b1 = beta[2 * dy + 1];
+    uint8_t* D = dst + (size_t)dy * dstride;
+    for (int dx = 0; dx < dw; ++dx)
+      D[dx] = (uint8_t)((((b0 * (row0[dx] >> 4)) >> 16) +
+                         ((b1 * (row1[dx] >> 4)) >> 16) + 2) >> 2);
+  }
+}
+
+// In-place border fill of a padded plane from its own interior
+// (copyMakeBorder with BORDER_REFLECT_101 [+ BORDER_ISOLATED]).
+void fillBorder101(Plane& p) {
+  uint8_t* base = p.data.data();
+  for (int py = 0; py < p.h + 2 * kEdge; ++py) {
+    int sy = reflect101(py - kEdge, p.h);
+    uint8_t* drow = base + (size_t)py * p.stride;
+    const uint8_t* srow = base + (size_t)(sy + kEdge) * p.stride + kEdge;
+    if (py < kEdge || py >= p.h + kEdge)
+      for (int x = 0; x < p.w; ++x) drow[kEdge + x] = srow[x];
+    for (int px = 0; px < kEdge; ++px) {
+      drow[px] = srow[reflect101(px - kEdge, p.w)];
+      drow[kEdge + p.w + px] = srow[reflect101(p.w + px, p.w)];
+    }
+  }
+}
+
+// cv::GaussianBlur(Size(7,7), 2, 2, BORDER_REFLECT_101) on a contiguous 8-bit
+// image: 8.8 fixed-point separable kernel {18,34,48,56,48,34,18}, 16-bit row
+// sums, (sum + 2^15) >> 16 after the column pass.
+const int kGauss[7] = {18, 34, 48, 56, 48, 34, 18};
+void gaussianBlur7(const uint8_t* src, int w, int h, int sstride, uint8_t* dst,
+                   int dstride) {
+  std::vector<uint16_t> tmp((size_t)w * h);
+  for (int y = 0; y < h; ++y) {
+    const uint8_t* S = src + (size_t)y * sstride;
+    for (int x = 0; x < w; ++x) {
+      unsigned acc = 0;
+      for (int k = 0; k < 7; ++k) acc += kGauss[k] * S[reflect101(x + k - 3, w)];
+      tmp[(size_t)y * w + x] = (uint16_t)acc;
+    }
+  }
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      uint32_t acc = 0;
+      for (int k = 0; k < 7; ++k)
+        acc += (uint32_t)kGauss[k] * tmp[(size_t)reflect101(y + k - 3, h) * w + x];
+      dst[(size_t)y * dstride + x] = (uint8_t)((acc + 32768u) >> 16);
+    }
+}
+
+// ---- FAST 9/16 with non-max suppression (cv::FAST(roi, kps, thr, true)) ----
+const int kCircle[16][2] = {{0, 3},  {1, 3},   {2, 2},   {3, 1},  {3, 0},  {3, -1},
+                            {2, -2}, {1, -3},  {0, -3},  {-1, -3}, {-2, -2}, {-3, -1},
+                            {-3, 0}, {-3, 1},  {-2, 2},  {-1, 3}};
+
+struct Cand { int x, y, score; };
+
+// OpenCV cornerScore<16>: largest threshold for which the pixel is still a
+// corner, minus one (but never below threshold-1).
+int cornerScore16(const uint8_t* p, const int* off, int threshold) {
+  int d[25];
+  int v = p[0];
+  for (int k = 0; k < 25; ++k) d[k] = v - p[off[k & 15]];
+  int a0 = threshold;
+  for (int k = 0; k < 16; k += 2) {
+    int a = std::min(d[k + 1], d[k + 2]);
+    a = std::min(a, d[k + 3]);
+    if (a <= a0) continue;
+    for (int j = 4; j <= 8; ++j) a = std::min(a, d[k + j]);
+    a0 = std::max(a0, std::min(a, d[k]));
+    a0 = std::max(a0, std::min(a, d[k + 9]));
+  }
+  int b0 = -a0;
+  for (int k = 0; k < 16; k += 2) {
+    int b = std::max(d[k + 1], d[k + 2]);
+    for (int j = 3; j <= 5; ++j) b = std::max(b, d[k + j]);
+    if (b >= b0) continue;
+    for (int j = 6; j <= 8; ++j) b = std::max(b, d[k + j]);
+    b0 = std::min(b0, std::max(b, d[k]));
+    b0 = std::min(b0, std::max(b, d[k + 9]));
+  }
+  return -b0 - 1;
+}
+
+// Segment test: 9 contiguous ring pixels all darker than v - t or all
+// brighter than v + t.  tab classifies a difference (index value - v + 255)
+// as 1 = darker, 2 = brighter, 0 = similar; the opposite-pair tests are the
+// usual quick rejection (any 9-arc holds one pixel of every opposite pair).
+bool isCorner16(const uint8_t* p, const int* off, int threshold, const uint8_t* tab0) {
+  const int v = p[0];
+  const uint8_t* tab = tab0 - v + 255;
+  int d = tab[p[off[0]]] | tab[p[off[8]]];
+  if (d == 0) return false;
+  d &= tab[p[off[2]]] | tab[p[off[10]]];
+  d &= tab[p[off[4]]] | tab[p[off[12]]];
+  d &= tab[p[off[6]]] | tab[p[off[14]]];
+  if (d == 0) return false;
+  d &= tab[p[off[1]]] | tab[p[off[9]]];
+  d &= tab[p[off[3]]] | tab[p[off[11]]];
+  d &= tab[p[off[5]]] | tab[p[off[13]]];
+  d &= tab[p[off[7]]] | tab[p[off[15]]];
+  if (d & 1) {
+    const int lo = v - threshold;
+    int run = 0;
+    for (int k = 0; k < 25; ++k) {
+      if (p[off[k & 15]] < lo) { if (++run > 8) return true; } else run = 0;
+    }
+  }
+  if (d & 2) {
+    const int hi = v + threshold;
+    int run = 0;
+    for (int k = 0; k < 25; ++k) {
+      if (p[off[k & 15]] > hi) { if (++run > 8) return true; } else run = 0;
+    }
+  }
+  return false;
+}
+
+void fast9_16(const uint8_t* img, int cols, int rows, int stride, int threshold,
+              std::vector<Cand>& out) {
+  out.clear();
+  threshold = std::min(std::max(threshold, 0), 255);
+  if (cols < 7 || rows < 7) return;
+  int off[16];
+  for (int k = 0; k < 16; ++k) off[k] = kCircle[k][0] + kCircle[k][1] * stride;
+  uint8_t tab[512];
+  for (int i = -255; i <= 255; ++i) tab[i + 255] = (uint8_t)(i < -threshold ? 1 : i > threshold ? 2 : 0);
+  std::vector<uint8_t> score((size_t)cols * rows, 0);
+  for (int y = 3; y < rows - 3; ++y)
+    for (int x = 3; x < cols - 3; ++x) {
+      const uint8_t* p = img + (size_t)y * stride + x;
+      if (isCorner16(p, off, threshold, tab))
+        score[(size_t)y * cols + x] = (uint8_t)cornerScore16(p, off, threshold);
+    }
+  for (int y = 3; y < rows - 3; ++y)
+    for (int x = 3; x < cols - 3; ++x) {
+      const uint8_t* s = &score[(size_t)y * cols + x];
+      // Only detected corners are visited; a corner's score is >= threshold,
+      // and a score of 0 can never beat its (non-negative) neighbours.
+      int sc = *s;
+      if (sc == 0) continue;
+      if (sc > s[-1] && sc > s[1] && sc > s[-cols - 1] && sc > s[-cols] &&
+          sc > s[-cols + 1] && sc > s[cols - 1] && sc > s[cols] && sc > s[cols + 1])
+        out.push_back({x, y, sc});
+    }
+}
+
+// ---- quadtree distribution -------------------------------------------------
+struct QNode {
+  int ulx, uly, urx, ury, blx, bly, brx, bry;
+  std::vector<int> keys;  // indices into the candidate array, parent order kept
+  std::list<QNode>::iterator self;
+  bool noMore = false;
+};
+
+// core/lib/ORB/extractor.cc:474-526
+void splitNode(const QNode& p, const std::vector<Cand>& c, QNode ch[4]) {
+  const int halfX = (int)std::ceil(static_cast<float>(p.urx - p.ulx) / 2);
+  const int halfY = (int)std::ceil(static_cast<float>(p.bry - p.uly) / 2);
+  const int mx = p.ulx + halfX, my = p.uly + halfY;
+  ch[0].ulx = p.ulx; ch[0].uly = p.uly; ch[0].urx = mx; ch[0].ury = p.uly;
+  ch[0].blx = p.ulx; ch[0].bly = my; ch[0].brx = mx; ch[0].bry = my;
+  ch[1].ulx = mx; ch[1].uly = p.uly; ch[1].urx = p.urx; ch[1].ury = p.ury;
+  ch[1].blx = mx; ch[1].bly = my; ch[1].brx = p.urx; ch[1].bry = my;
+  ch[2].ulx = p.ulx; ch[2].uly = my; ch[2].urx = mx; ch[2].ury = my;
+  ch[2].blx = p.blx; ch[2].bly = p.bly; ch[2].brx = mx; ch[2].bry = p.bly;
+  ch[3].ulx = mx; ch[3].uly = my; ch[3].urx = p.urx; ch[3].ury = my;
+  ch[3].blx = mx; ch[3].bly = p.bly; ch[3].brx = p.brx; ch[3].bry = p.bry;
+  for (int k : p.keys) {
+    const float kx = (float)c[k].x, ky = (float)c[k].y;
+    int q = (kx < (float)mx) ? ((ky < (float)my) ? 0 : 2) : ((ky < (float)my) ? 1 : 3);
+    ch[q].keys.push_back(k);
+  }
+  for (int q = 0; q < 4; ++q) ch[q].noMore = ch[q].keys.size() == 1;
+}
+
+typedef std::pair<int, QNode*> SizedNode;
+bool sizedNodeLess(const SizedNode& a, const SizedNode& b) {  // :528-541
+  if (a.first < b.first) return true;
+  if (a.first > b.first) return false;
+  return a.second->ulx < b.second->ulx;
+}
+
+// core/lib/ORB/extractor.cc:543-745.  cand coordinates are relative to
+// (minX, minY).  Returns indices into cand, in final list order.
+std::vector<int> distributeQuadTree(const std::vector<Cand>& cand, int minX,
+                                    int maxX, int minY, int maxY, int N) {
+  std::vector<int> result;
+  const int nIni = (int)std::round(static_cast<float>(maxX - minX) / (maxY - minY));
+  const float hX = static_cast<float>(maxX - minX) / nIni;
+  std::list<QNode> nodes;
+  std::vector<QNode*> roots(nIni);
+  for (int i = 0; i < nIni; ++i) {
+    QNode n;
+    n.ulx = (int)(hX * static_cast<float>(i)); n.uly = 0;
+    n.urx = (int)(hX * static_cast<float>(i + 1)); n.ury = 0;
+    n.blx = n.ulx; n.bly = maxY - minY;
+    n.brx = n.urx; n.bry = maxY - minY;
+    nodes.push_back(n);
+    roots[i] = &nodes.back();
+  }
+  for (size_t i = 0; i < cand.size(); ++i)
+    roots[(int)((float)cand[i].x / hX)]->keys.push_back((int)i);
+  for (auto it = nodes.begin(); it != nodes.end();) {
+    if (it->keys.size() == 1) { it->noMore = true; ++it; }
+    else if (it->keys.empty()) it = nodes.erase(it);
+    else ++it;
+  }
+  bool finish = false;
+  std::vector<SizedNode> rec;
+  auto pushChildren = [&](QNode ch[4], int* nToExpand) {
+    for (int q = 0; q < 4; ++q) {
+      if (ch[q].keys.empty()) continue;
+      nodes.push_front(ch[q]);
+      if (ch[q].keys.size() > 1) {
+        if (nToExpand) ++*nToExpand;
+        rec.push_back(std::make_pair((int)ch[q].keys.size(), &nodes.front()));
+        nodes.front().self = nodes.begin();
+      }
+    }
+  };
+  while (!finish) {
+    int prevSize = (int)nodes.size();
+    int nToExpand = 0;
+    rec.clear();
+    for (auto it = nodes.begin(); it != nodes.end();) {
+      if (it->noMore) { ++it; continue; }
+      QNode ch[4];
+      splitNode(*it, cand, ch);
+      pushChildren(ch, &nToExpand);
+      it = nodes.erase(it);
+    }
+    if ((int)nodes.size() >= N || (int)nodes.size() == prevSize) {
+      finish = true;
+    } else if ((int)nodes.size() + nToExpand * 3 > N) {
+      while (!finish) {
+        prevSize = (int)nodes.size();
+        std::vector<SizedNode> prev = rec;
+        rec.clear();
+        std::sort(prev.begin(), prev.end(), sizedNodeLess);
+        for (int j = (int)prev.size() - 1; j >= 0; --j) {
+          QNode ch[4];
+          splitNode(*prev[j].second, cand, ch);
+          pushChildren(ch, nullptr);
+          nodes.erase(prev[j].second->self);
+          if ((int)nodes.size() >= N) break;
+        }
+        if ((int)nodes.size() >= N || (int)nodes.size() == prevSize) finish = true;
+      }
+    }
+  }
+  for (auto& n : nodes) {
+    int best = n.keys[0];
+    float bestResp = (float)cand[best].score;
+    for (size_t k = 1; k < n.keys.size(); ++k)
+      if ((float)cand[n.keys[k]].score > bestResp) {
+        best = n.keys[k];
+        bestResp = (float)cand[best].score;
+      }
+    result.push_back(best);
+  }
+  return result;
+}
+
+// ---- the extractor ---------------------------------------------------------
+struct Extractor {
+  int nfeatures, nlevels, iniTh, minTh;
+  double scaleFactor;  // double member holding the float argument (extractor.h:89)
+  std::vector<float> scale, invScale, sigma2, invSigma2;
+  std::vector<int> quota;
+  int umax[kHalfPatch + 1];
+  // per-call state kept for stage-by-stage comparison
+  std::vector<Plane> pyr;
+  std::vector<std::vector<Cand>> cands;      // coordinates relative to (16,16)
+  std::vector<std::vector<KeyPoint>> keys;   // level coords, angle filled
+  std::vector<std::vector<uint8_t>> blurred; // w*h contiguous
+  std::vector<std::vector<int>> moments;     // (m10, m01) per level key
+
+  Extractor(int nf, float sf, int nl, int ini, int mn)
+      : nfeatures(nf), nlevels(nl), iniTh(ini), minTh(mn), scaleFactor(sf) {
+    // core/lib/ORB/extractor.cc:406-463
+    scale.resize(nl); invScale.resize(nl); sigma2.resize(nl); invSigma2.resize(nl);
+    scale[0] = 1.0f; sigma2[0] = 1.0f;
+    for (int i = 1; i < nl; ++i) {
+      scale[i] = (float)(scale[i - 1] * scaleFactor);
+      sigma2[i] = scale[i] * scale[i];
+    }
+    for (int i = 0; i < nl; ++i) {
+      invScale[i] = 1.0f / scale[i];
+      invSigma2[i] = 1.0f / sigma2[i];
+    }
+    quota.resize(nl);
+    float factor = (float)(1.0f / scaleFactor);
+    float desired = nfeatures * (1 - factor) /
+                    (1 - (float)std::pow((double)factor, (double)nl));
+    int sum = 0;
+    for (int l = 0; l < nl - 1; ++l) {
+      quota[l] = cvRoundF(desired);
+      sum += quota[l];
+      desired *= factor;
+    }
+    quota[nl - 1] = std::max(nfeatures - sum, 0);
+    int vmax = cvFloorF(kHalfPatch * std::sqrt(2.f) / 2 + 1);
+    int vmin = cvCeilF(kHalfPatch * std::sqrt(2.f) / 2);
+    const double hp2 = kHalfPatch * kHalfPatch;
+    for (int v = 0; v <= kHalfPatch; ++v) umax[v] = 0;
+    for (int v = 0; v <= vmax; ++v) umax[v] = cvRoundD(std::sqrt(hp2 - v * v));
+    for (int v = kHalfPatch, v0 = 0; v >= vmin; --v) {
+      while (umax[v0] == umax[v0 + 1]) ++v0;
+      umax[v] = v0;
+      ++v0;
+    }
+  }
+
+  void levelSize(int W, int H, int l, int* w, int* h) const {  // :1105-1107
+    *w = cvRoundF((float)W * invScale[l]);
+    *h = cvRoundF((float)H * invScale[l]);
+  }
+
+  // :1103-1127
+  void computePyramid(const uint8_t* img, int W, int H, int stride) {
+    pyr.assign(nlevels, Plane());
+    for (int l = 0; l < nlevels; ++l) {
+      Plane& p = pyr[l];
+      levelSize(W, H, l, &p.w, &p.h);
+      p.stride = p.w + 2 * kEdge;
+      p.data.assign((size_t)p.stride * (p.h + 2 * kEdge), 0);
+      if (l == 0) {
+        for (int y = 0; y < H; ++y)
+          std::memcpy(p.roi() + (size_t)y * p.stride, img + (size_t)y * stride, W);
+      } else {
+        const Plane& s = pyr[l - 1];
+        resizeLinearU8(s.roi(), s.w, s.h, s.stride, p.roi(), p.w, p.h, p.stride);
+      }
+      fillBorder101(p);
+    }
+  }
+
+  // :747-831 (grid of 35-px cells, FAST with retry at the lower threshold)
+  void detectLevel(int l) {
+    const Plane& p = pyr[l];
+    std::vector<Cand>& out = cands[l];
+    out.clear();
+    const int minBX = kEdge - 3, minBY = minBX;
+    const int maxBX = p.w - kEdge + 3, maxBY = p.h - kEdge + 3;
+    const float width = (float)(maxBX - minBX), height = (float)(maxBY - minBY);
+    const int nCols = (int)(width / kCellW), nRows = (int)(height / kCellW);
+    const int wCell = (int)std::ceil(width / nCols), hCell = (int)std::ceil(height / nRows);
+    std::vector<Cand> cell;
+    for (int i = 0; i < nRows; ++i) {
+      const float iniY = (float)(minBY + i * hCell);
+      float maxY = iniY + hCell + 6;
+      if (iniY >= maxBY - 3) continue;
+      if (maxY > maxBY) maxY = (float)maxBY;
+      for (int j = 0; j < nCols; ++j) {
+        const float iniX = (float)(minBX + j * wCell);
+        float maxX = iniX + wCell + 6;
+        if (iniX >= maxBX - 6) continue;
+        if (maxX > maxBX) maxX = (float)maxBX;
+        const int x0 = (int)iniX, y0 = (int)iniY, x1 = (int)maxX, y1 = (int)maxY;
+        const uint8_t* roi = p.roi() + (size_t)y0 * p.stride + x0;
+        fast9_16(roi, x1 - x0, y1 - y0, p.stride, iniTh, cell);
+        if (cell.empty()) fast9_16(roi, x1 - x0, y1 - y0, p.stride, minTh, cell);
+        for (const Cand& c : cell)
+          out.push_back({c.x + j * wCell, c.y + i * hCell, c.score});
+      }
+    }
+  }
+
+  // :75-99
+  float icAngle(const Plane& p, int cx, int cy, int* m10o, int* m01o) const {
+    const uint8_t* c = p.roi() + (size_t)cy * p.stride + cx;
+    int m01 = 0, m10 = 0;
+    for (int u = -kHalfPatch; u <= kHalfPatch; ++u) m10 += u * c[u];
+    for (int v = 1; v <= kHalfPatch; ++v) {
+      int vsum = 0, d = umax[v];
+      for (int u = -d; u <= d; ++u) {
+        int a = c[u + v * p.stride], b = c[u - v * p.stride];
+        vsum += a - b;
+        m10 += u * (a + b);
+      }
+      m01 += v * vsum;
+    }
+    *m10o = m10; *m01o = m01;
+    return fastAtan2((float)m01, (float)m10);
+  }
+
+  // :102-145
+  void describe(const KeyPoint& kp, const uint8_t* img, int step, uint8_t* desc) const {
+    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+    float angle = kp.angle * factorPI;
+    float a = (float)std::cos((double)angle), b = (float)std::sin((double)angle);
+    const uint8_t* c = img + (size_t)cvRoundF(kp.y) * step + cvRoundF(kp.x);
+    const int* pat = kPattern;
+    for (int i = 0; i < 32; ++i) {
+      int val = 0;
+      for (int j = 0; j < 8; ++j, pat += 4) {
+        float x0 = (float)pat[0], y0 = (float)pat[1], x1 = (float)pat[2], y1 = (float)pat[3];
+        int t0 = c[cvRoundF(x0 * b + y0 * a) * step + cvRoundF(x0 * a - y0 * b)];
+        int t1 = c[cvRoundF(x1 * b + y1 * a) * step + cvRoundF(x1 * a - y1 * b)];
+        val |= (t0 < t1) << j;
+      }
+      desc[i] = (uint8_t)val;
+    }
+  }
+
+  // :1018-1101.  Returns status (0 ok, -1 empty image, -2 too small, -3 capacity).
+  int extract(const uint8_t* img, int W, int H, int stride, int lap0, int lap1,
+              KeyPoint* kps, uint8_t* desc, int cap, int* nOut, int* monoOut) {
+    *nOut = 0; *monoOut = -1;
+    if (!img || W <= 0 || H <= 0) return -1;
+    {
+      int w, h;
+      levelSize(W, H, nlevels - 1, &w, &h);
+      if (w - 2 * (kEdge - 3) < kCellW || h - 2 * (kEdge - 3) < kCellW) return -2;
+      // nIni = round(width/height) must be >= 1 (extractor.cc:549 divides by it)
+      for (int l = 0; l < nlevels; ++l) {
+        levelSize(W, H, l, &w, &h);
+        if ((int)std::round(static_cast<float>(w - 32) / (h - 32)) < 1) return -2;
+      }
+    }
+    computePyramid(img, W, H, stride);
+    cands.assign(nlevels, {}); keys.assign(nlevels, {});
+    blurred.assign(nlevels, {}); moments.assign(nlevels, {});
+    for (int l = 0; l < nlevels; ++l) {
+      detectLevel(l);
+      const Plane& p = pyr[l];
+      const int minB = kEdge - 3;
+      std::vector<int> sel = distributeQuadTree(cands[l], minB, p.w - kEdge + 3, minB,
+                                                p.h - kEdge + 3, quota[l]);
+      const int patchSize = (int)(kPatch * scale[l]);  // :840
+      for (int idx : sel) {
+        KeyPoint k;
+        k.x = (float)cands[l][idx].x + minB;
+        k.y = (float)cands[l][idx].y + minB;
+        k.size = (float)patchSize;
+        k.angle = -1.f;
+        k.response = (float)cands[l][idx].score;
+        k.octave = l;
+        k.class_id = -1;
+        keys[l].push_back(k);
+      }
+    }
+    for (int l = 0; l < nlevels; ++l) {
+      moments[l].resize(2 * keys[l].size());
+      for (size_t i = 0; i < keys[l].size(); ++i)
+        keys[l][i].angle = icAngle(pyr[l], cvRoundF(keys[l][i].x), cvRoundF(keys[l][i].y),
+                                   &moments[l][2 * i], &moments[l][2 * i + 1]);
+    }
+    int n = 0;
+    for (int l = 0; l < nlevels; ++l) n += (int)keys[l].size();
+    *nOut = n;
+    if (n > cap) return -3;
+    int mono = 0, stereo = n - 1;
+    for (int l = 0; l < nlevels; ++l) {
+      if (keys[l].empty()) continue;
+      const Plane& p = pyr[l];
+      blurred[l].resize((size_t)p.w * p.h);
+      gaussianBlur7(p.roi(), p.w, p.h, p.stride, blurred[l].data(), p.w);
+      const float s = scale[l];
+      for (size_t i = 0; i < keys[l].size(); ++i) {
+        uint8_t d[32];
+        describe(keys[l][i], blurred[l].data(), p.w, d);
+        KeyPoint k = keys[l][i];
+        if (l != 0) { k.x *= s; k.y *= s; }
+        int dstIdx;
+        if (k.x >= (float)lap0 && k.x <= (float)lap1) dstIdx = stereo--;
+        else dstIdx = mono++;
+        kps[dstIdx] = k;
+        std::memcpy(desc + (size_t)dstIdx * 32, d, 32);
+      }
+    }
+    *monoOut = mono;
+    return 0;
+  }
+};
+
+// core/lib/ORB/matcher.cc:1961-1975
+inline int hamming256(const uint8_t* a, const uint8_t* b) {
+  int dist = 0;
+  for (int i = 0; i < 8; ++i) {
+    uint32_t x, y;
+    std::memcpy(&x, a + 4 * i, 4);
+    std::memcpy(&y, b + 4 * i, 4);
+    uint32_t v = x ^ y;
+    v = v - ((v >> 1) & 0x55555555u);
+    v = (v & 0x33333333u) + ((v >> 2) & 0x33333333u);
+    dist += (int)((((v + (v >> 4)) & 0xF0F0F0Fu) * 0x1010101u) >> 24);
+  }
+  return dist;
+}
+
+}  // namespace
+
+extern "C" {
+
+struct orc_extractor;  // opaque
+
+orc_extractor* orc_create(int nfeatures, float scaleFactor, int nlevels, int iniTh, int minTh) {
+  if (nlevels < 1 || nfeatures < 1 || !(scaleFactor > 1.0f)) return nullptr;
+  return reinterpret_cast<orc_extractor*>(new Extractor(nfeatures, scaleFactor, nlevels, iniTh, minTh));
+}
+void orc_destroy(orc_extractor* h) { delete reinterpret_cast<Extractor*>(h); }
+
+void orc_tables(orc_extractor* h, float* scale, float* inv, float* sigma2, float* invSigma2,
+                int* quotas, int* umax16) {
+  Extractor* e = reinterpret_cast<Extractor*>(h);
+  for (int i = 0; i < e->nlevels; ++i) {
+    if (scale) scale[i] = e->scale[i];
+    if (inv) inv[i] = e->invScale[i];
+    if (sigma2) sigma2[i] = e->sigma2[i];
+    if (invSigma2) invSigma2[i] = e->invSigma2[i];
+    if (quotas) quotas[i] = e->quota[i];
+  }
+  if (umax16) for (int i = 0; i < 16; ++i) umax16[i] = e->umax[i];
+}
+
+int orc_extract(orc_extractor* h, const uint8_t* img, int W, int H, int stride, int lap0,
+                int lap1, void* kps28, uint8_t* desc, int cap, int* n, int* mono) {
+  return reinterpret_cast<Extractor*>(h)->extract(img, W, H, stride, lap0, lap1,
+                                                  (KeyPoint*)kps28, desc, cap, n, mono);
+}
+
+// Stage dumps of the last orc_extract call.
+int orc_level_dims(orc_extractor* h, int level, int* w, int* hh, int* stride) {
+  Extractor* e = reinterpret_cast<Extractor*>(h);
+  if (level < 0 || level >= (int)e->pyr.size()) return -1;
+  *w = e->pyr[level].w; *hh = e->pyr[level].h; *stride = e->pyr[level].stride;
+  return 0;
+}
+const uint8_t* orc_level_padded(orc_extractor* h, int level) {
+  return reinterpret_cast<Extractor*>(h)->pyr[level].data.data();
+}
+int orc_level_candidates(orc_extractor* h, int level, int* xys, int cap) {
+  Extractor* e = reinterpret_cast<Extractor*>(h);
+  const std::vector<Cand>& c = e->cands[level];
+  for (size_t i = 0; i < c.size() && (int)i < cap; ++i) {
+    xys[3 * i] = c[i].x; xys[3 * i + 1] = c[i].y; xys[3 * i + 2] = c[i].score;
+  }
+  return (int)c.size();
+}
+int orc_level_keys(orc_extractor* h, int level, void* kps28, int* m10m01, int cap) {
+  Extractor* e = reinterpret_cast<Extractor*>(h);
+  const std::vector<KeyPoint>& k = e->keys[level];
+  for (size_t i = 0; i < k.size() && (int)i < cap; ++i) {
+    ((KeyPoint*)kps28)[i] = k[i];
+    if (m10m01) { m10m01[2 * i] = e->moments[level][2 * i]; m10m01[2 * i + 1] = e->moments[level][2 * i + 1]; }
+  }
+  return (int)k.size();
+}
+const uint8_t* orc_level_blurred(orc_extractor* h, int level) {
+  Extractor* e = reinterpret_cast<Extractor*>(h);
+  return e->blurred[level].empty() ? nullptr : e->blurred[level].data();
+}
+
+// ---- stand-alone primitives for unit tests ---------------------------------
+int orc_cv_round(float v) { return cvRoundF(v); }
+float orc_fast_atan2(float y, float x) { return fastAtan2(y, x); }
+void orc_resize_linear_u8(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw,
+                          int dh, int dstride) {
+  resizeLinearU8(src, sw, sh, sstride, dst, dw, dh, dstride);
+}
+void orc_gauss7(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride) {
+  gaussianBlur7(src, w, h, sstride, dst, dstride);
+}
+int orc_fast(const uint8_t* img, int cols, int rows, int stride, int threshold, int* xys, int cap) {
+  std::vector<Cand> out;
+  fast9_16(img, cols, rows, stride, threshold, out);
+  for (size_t i = 0; i < out.size() && (int)i < cap; ++i) {
+    xys[3 * i] = out[i].x; xys[3 * i + 1] = out[i].y; xys[3 * i + 2] = out[i].score;
+  }
+  return (int)out.size();
+}
+// Quadtree selection on an explicit candidate list (x, y relative to minX/minY).
+int orc_octree(const int* xys, int n, int minX, int maxX, int minY, int maxY, int N, int* sel,
+               int cap) {
+  std::vector<Cand> c(n);
+  for (int i = 0; i < n; ++i) c[i] = {xys[3 * i], xys[3 * i + 1], xys[3 * i + 2]};
+  std::vector<int> r = distributeQuadTree(c, minX, maxX, minY, maxY, N);
+  for (size_t i = 0; i < r.size() && (int)i < cap; ++i) sel[i] = r[i];
+  return (int)r.size();
+}
+// std::sort permutation of (size, ulx) records with the reference comparator;
+// perm[i] = original index of the element that ends at position i.
+void orc_sort_sized_nodes(const int* size, const int* ulx, int n, int* perm) {
+  std::vector<QNode> pool(n);
+  std::vector<SizedNode> v(n);
+  for (int i = 0; i < n; ++i) { pool[i].ulx = ulx[i]; v[i] = std::make_pair(size[i], &pool[i]); }
+  std::sort(v.begin(), v.end(), sizedNodeLess);
+  for (int i = 0; i < n; ++i) perm[i] = (int)(v[i].second - pool.data());
+}
+
+int orc_hamming(const uint8_t* a, const uint8_t* b) { return hamming256(a, b); }
+
+// Brute-force Hamming 2-NN with cv::BFMatcher::knnMatch(k=2) ordering:
+// ascending distance, earliest train index first among equals
+// (core/src/Frame.cc:1177).  Missing neighbours: idx 0xFFFFFFFF, dist 0xFFFF.
+void orc_knn2(const uint8_t* q, int nq, const uint8_t* t, int64_t nt, uint32_t* idx, uint16_t* dist) {
+  for (int i = 0; i < nq; ++i) {
+    int d0 = INT_MAX, d1 = INT_MAX;
+    int64_t i0 = -1, i1 = -1;
+    for (int64_t j = 0; j < nt; ++j) {
+      int d = hamming256(q + (size_t)i * 32, t + (size_t)j * 32);
+      if (d < d1) {
+        if (d < d0) { d1 = d0; i1 = i0; d0 = d; i0 = j; }
+        else { d1 = d; i1 = j; }
+      }
+    }
+    idx[2 * i] = i0 < 0 ? 0xFFFFFFFFu : (uint32_t)i0;
+    idx[2 * i + 1] = i1 < 0 ? 0xFFFFFFFFu : (uint32_t)i1;
+    dist[2 * i] = i0 < 0 ? 0xFFFF : (uint16_t)d0;
+    dist[2 * i + 1] = i1 < 0 ? 0xFFFF : (uint16_t)d1;
+  }
+}
+
+// Row-band stereo descriptor search, core/src/Frame.cc:840-908.
+// bestDist[i] stays 100 (TH_HIGH) and bestIdx[i] = -1 when nothing qualified.
+void orc_stereo_band_match(const void* kpsL28, const uint8_t* descL, int nL, const void* kpsR28,
+                           const uint8_t* descR, int nR, const float* scaleFactors, int nRows,
+                           float minD, float maxD, int* bestIdx, int* bestDist) {
+  const KeyPoint* L = (const KeyPoint*)kpsL28;
+  const KeyPoint* R = (const KeyPoint*)kpsR28;
+  std::vector<std::vector<int>> rows(nRows);
+  for (int iR = 0; iR < nR; ++iR) {
+    const float y = R[iR].y;
+    const float r = 2.0f * scaleFactors[R[iR].octave];
+    const int maxr = (int)std::ceil(y + r), minr = (int)std::floor(y - r);
+    for (int yi = minr; yi <= maxr; ++yi)
+      if (yi >= 0 && yi < nRows) rows[yi].push_back(iR);
+  }
+  for (int iL = 0; iL < nL; ++iL) {
+    bestIdx[iL] = -1; bestDist[iL] = 100;
+    const float vL = L[iL].y, uL = L[iL].x;
+    const int lvl = L[iL].octave;
+    const int row = (int)vL;
+    if (row < 0 || row >= nRows) continue;
+    const std::vector<int>& c = rows[row];
+    if (c.empty()) continue;
+    const float minU = uL - maxD, maxU = uL - minD;
+    if (maxU < 0) continue;
+    int best = 100, bi = -1;
+    for (int iR : c) {
+      if (R[iR].octave < lvl - 1 || R[iR].octave > lvl + 1) continue;
+      const float uR = R[iR].x;
+      if (uR >= minU && uR <= maxU) {
+        int d = hamming256(descL + (size_t)iL * 32, descR + (size_t)iR * 32);
+        if (d < best) { best = d; bi = iR; }
+      }
+    }
+    bestIdx[iL] = bi; bestDist[iL] = best;
+  }
+}
+
+}  // extern "C"

@@ -1,0 +1,710 @@
+// C ABI of the extractor (include/orbx.h): handle, plan construction, stage
+// orchestration on one HIP stream, host<->device transfers, stage dumps.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/orbx.h"
+#include "orbx_plan.h"
+
+namespace orbx {
+void launch_pyramid(const Plan& hp, const uint8_t* d_img, int istride, size_t iframe, uint8_t* d_pyr,
+                    int nframes, hipStream_t s);
+void launch_fast(const Plan& hp, const Plan* dp, const uint8_t* d_pyr, uint32_t* d_cand,
+                 int* d_cellCount, int nframes, hipStream_t s);
+void launch_octree(const Plan& hp, const Plan* dp, const uint32_t* d_cand, const int* d_cellCount,
+                   uint32_t* d_flatA, uint32_t* d_flatB, uint32_t* d_sel, int* d_selCount,
+                   int nframes, hipStream_t s);
+void launch_assemble(const Plan& hp, const Plan* dp, const uint32_t* d_sel, const int* d_selCount,
+                     int lap0, int lap1, float* d_kps, WorkItem* d_work, int* d_n, int* d_mono,
+                     int nframes, hipStream_t s);
+void launch_blur(const Plan& hp, const Plan* dp, const uint8_t* d_pyr, uint8_t* d_blur, int nframes,
+                 hipStream_t s);
+void launch_describe(const Plan& hp, const Plan* dp, const uint8_t* d_pyr, const uint8_t* d_blur,
+                     const WorkItem* d_work, const int* d_n, float* d_kps, uint8_t* d_desc,
+                     int nframes, hipStream_t s);
+int octree_set_lds_limit(const Plan& hp);
+}  // namespace orbx
+
+using orbx::LevelDesc;
+using orbx::Plan;
+using orbx::Tap;
+using orbx::WorkItem;
+
+namespace {
+
+// cvRound / cvFloor / cvCeil as OpenCV defines them for float and double.
+inline int cv_round(float v) { return (int)lrintf(v); }
+inline int cv_round(double v) { return (int)lrint(v); }
+inline int cv_floor(float v) { int i = (int)v; return i - (i > v); }
+inline int cv_ceil(float v) { int i = (int)v; return i + (i < v); }
+inline int16_t sat_short(float v) {
+  int r = cv_round(v);
+  return (int16_t)std::min(std::max(r, -32768), 32767);
+}
+inline int reflect101(int i, int n) {
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * n - 2 - i;
+  return i;
+}
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+#define HIP_TRY(expr)                       \
+  do {                                      \
+    hipError_t e_ = (expr);                 \
+    if (e_ != hipSuccess) {                 \
+      last_hip_error = e_;                  \
+      return ORBX_ERR_HIP;                  \
+    }                                       \
+  } while (0)
+
+}  // namespace
+
+struct orbx_extractor {
+  orbx_params prm;
+  double scaleFactorD;  // the reference keeps the float argument in a double member
+  std::vector<float> scale, invScale, sigma2, invSigma2;
+  std::vector<int> quota;
+  int umax[16];
+  int maxKeypoints = 0;
+
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipError_t last_hip_error = hipSuccess;
+
+  // plan for the current image size
+  bool planned = false;
+  Plan hp;
+  Plan* dp = nullptr;
+  std::vector<Tap*> d_taps;
+
+  uint8_t* d_img = nullptr;   // staging for host-image entry points
+  uint8_t* d_pyr = nullptr;
+  uint8_t* d_blur = nullptr;
+  uint32_t* d_cand = nullptr;
+  int* d_cellCount = nullptr;
+  uint32_t* d_flatA = nullptr;
+  uint32_t* d_flatB = nullptr;
+  uint32_t* d_sel = nullptr;
+  int* d_selCount = nullptr;
+  float* d_kps = nullptr;
+  uint8_t* d_desc = nullptr;
+  WorkItem* d_work = nullptr;
+  int* d_n = nullptr;
+  int* d_mono = nullptr;
+  size_t pyr_bytes = 0;
+
+  // pinned host staging
+  uint8_t* h_stage = nullptr;
+  size_t h_stage_bytes = 0;
+  std::vector<uint8_t> h_pyr;       // lazily downloaded pyramid of frame 0
+  std::vector<char> h_pyr_valid;
+
+  int lastFrames = 0;
+  bool profiling = false;
+  hipEvent_t ev[ORBX_NUM_STAGES + 1] = {};
+  bool evValid = false;
+
+  void buildTables();
+  int ensurePlan(int W, int H);
+  void freePlan();
+  int run(const uint8_t* d_images, int istride, size_t iframe, int nframes, int lap0, int lap1);
+};
+
+void orbx_extractor::buildTables() {
+  // core/lib/ORB/extractor.cc:406-463
+  const int nl = prm.nlevels;
+  scaleFactorD = (double)prm.scale_factor;
+  scale.resize(nl); invScale.resize(nl); sigma2.resize(nl); invSigma2.resize(nl); quota.resize(nl);
+  scale[0] = 1.0f; sigma2[0] = 1.0f;
+  for (int i = 1; i < nl; ++i) {
+    scale[i] = (float)(scale[i - 1] * scaleFactorD);
+    sigma2[i] = scale[i] * scale[i];
+  }
+  for (int i = 0; i < nl; ++i) {
+    invScale[i] = 1.0f / scale[i];
+    invSigma2[i] = 1.0f / sigma2[i];
+  }
+  float factor = (float)(1.0f / scaleFactorD);
+  float desired = prm.nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nl));
+  int sum = 0;
+  for (int l = 0; l < nl - 1; ++l) {
+    quota[l] = cv_round(desired);
+    sum += quota[l];
+    desired *= factor;
+  }
+  quota[nl - 1] = std::max(prm.nfeatures - sum, 0);
+
+  const int half = 15;
+  int vmax = cv_floor(half * std::sqrt(2.f) / 2 + 1);
+  int vmin = cv_ceil(half * std::sqrt(2.f) / 2);
+  const double hp2 = half * half;
+  for (int v = 0; v <= half; ++v) umax[v] = 0;
+  for (int v = 0; v <= vmax; ++v) umax[v] = cv_round(std::sqrt(hp2 - v * v));
+  for (int v = half, v0 = 0; v >= vmin; --v) {
+    while (umax[v0] == umax[v0 + 1]) ++v0;
+    umax[v] = v0;
+    ++v0;
+  }
+}
+
+void orbx_extractor::freePlan() {
+  if (!planned) return;
+  (void)hipSetDevice(device);
+  (void)hipStreamSynchronize(stream);
+  for (Tap* t : d_taps) (void)hipFree(t);
+  d_taps.clear();
+  void* bufs[] = {dp, d_img, d_pyr, d_blur, d_cand, d_cellCount, d_flatA, d_flatB, d_sel, d_selCount,
+                  d_kps, d_desc, d_work, d_n, d_mono};
+  for (void* b : bufs) if (b) (void)hipFree(b);
+  dp = nullptr; d_img = d_pyr = d_blur = d_desc = nullptr; d_cand = d_flatA = d_flatB = d_sel = nullptr;
+  d_cellCount = d_selCount = d_n = d_mono = nullptr; d_kps = nullptr; d_work = nullptr;
+  if (h_stage) (void)hipHostFree(h_stage);
+  h_stage = nullptr; h_stage_bytes = 0;
+  planned = false;
+}
+
+// cv::resize INTER_LINEAR coefficient tables for one axis, indexed by the
+// padded destination coordinate.  clampSingleTap selects the horizontal rule
+// (out-of-range source -> single tap with weight 2048) versus the vertical
+// rule (source rows clamped, weights kept).
+static void build_taps(int sn, int dn, bool horizontal, std::vector<Tap>& out) {
+  const double scale = 1.0 / ((double)dn / sn);
+  std::vector<Tap> t(dn);
+  for (int d = 0; d < dn; ++d) {
+    float fx = (float)((d + 0.5) * scale - 0.5);
+    int s = cv_floor(fx);
+    fx -= s;
+    Tap e;
+    if (horizontal) {
+      if (s < 0) { fx = 0; s = 0; }
+      if (s >= sn - 1) { fx = 0; s = sn - 1; }
+      e.s0 = (uint16_t)s;
+      e.s1 = (uint16_t)std::min(s + 1, sn - 1);
+    } else {
+      e.s0 = (uint16_t)std::min(std::max(s, 0), sn - 1);
+      e.s1 = (uint16_t)std::min(std::max(s + 1, 0), sn - 1);
+    }
+    e.w0 = sat_short((1.f - fx) * 2048);
+    e.w1 = sat_short(fx * 2048);
+    t[d] = e;
+  }
+  out.resize(dn + 2 * ORBX_EDGE);
+  for (int p = 0; p < dn + 2 * ORBX_EDGE; ++p) out[p] = t[reflect101(p - ORBX_EDGE, dn)];
+}
+
+int orbx_extractor::ensurePlan(int W, int H) {
+  if (planned && hp.W == W && hp.H == H) return ORBX_OK;
+  freePlan();
+  const int nl = prm.nlevels;
+  const int B = prm.max_batch;
+  std::memset(&hp, 0, sizeof(hp));
+  hp.nlevels = nl; hp.W = W; hp.H = H;
+  hp.ini_th = std::min(std::max(prm.ini_th_fast, 0), 255);
+  hp.min_th = std::min(std::max(prm.min_th_fast, 0), 255);
+  hp.max_batch = B;
+  for (int i = 0; i < 16; ++i) hp.umax[i] = umax[i];
+
+  size_t pyrOff = 0, blurOff = 0;
+  uint32_t candOff = 0, flatOff = 0;
+  int cellFirst = 0, tileFirst = 0, selOff = 0, nodesCap = 0, cellsMax = 0;
+  for (int l = 0; l < nl; ++l) {
+    LevelDesc& L = hp.lv[l];
+    L.w = cv_round((float)W * invScale[l]);  // extractor.cc:1105-1107
+    L.h = cv_round((float)H * invScale[l]);
+    if (L.w >= 4096 + 32 || L.h >= 4096 + 32) return ORBX_ERR_UNSUPPORTED;  // 12-bit key fields
+    // detection grid, extractor.cc:754-768
+    const int minB = ORBX_DET_ORG;
+    const int maxBX = L.w - ORBX_EDGE + 3, maxBY = L.h - ORBX_EDGE + 3;
+    const float width = (float)(maxBX - minB), height = (float)(maxBY - minB);
+    if (width < 35.f || height < 35.f) return ORBX_ERR_TOO_SMALL;
+    const int nCols = (int)(width / 35.f), nRows = (int)(height / 35.f);
+    L.wCell = (int)std::ceil(width / nCols);
+    L.hCell = (int)std::ceil(height / nRows);
+    if (L.wCell > ORBX_CELL_MAX - 2 || L.hCell > ORBX_CELL_MAX - 2) return ORBX_ERR_UNSUPPORTED;
+    // cells whose detection domain [19 + j*wCell, ...) x [19 + i*hCell, ...) is
+    // non-empty inside [19, w-19) x [19, h-19); the others find nothing in the
+    // reference either (skipped at :774/:782 or a FAST ROI under 7 pixels)
+    L.ncx = 0;
+    while (L.ncx < nCols && ORBX_EDGE + L.ncx * L.wCell < L.w - ORBX_EDGE) ++L.ncx;
+    L.ncy = 0;
+    while (L.ncy < nRows && ORBX_EDGE + L.ncy * L.hCell < L.h - ORBX_EDGE) ++L.ncy;
+    L.cell_first = cellFirst;
+    cellFirst += L.ncx * L.ncy;
+    cellsMax = std::max(cellsMax, L.ncx * L.ncy);
+    L.cand_cap_cell = ((L.wCell + 1) / 2) * ((L.hCell + 1) / 2);
+    L.cand_off = candOff;
+    const uint64_t levelCand = (uint64_t)L.ncx * L.ncy * L.cand_cap_cell;
+    if (candOff + levelCand > 0x7fffffffu) return ORBX_ERR_UNSUPPORTED;
+    candOff += (uint32_t)levelCand;
+    L.flat_off = flatOff;
+    L.flat_cap = (uint32_t)levelCand;
+    flatOff += (uint32_t)levelCand;
+    // quadtree roots, extractor.cc:549-551
+    L.quota = quota[l];
+    L.n_roots = (int)std::round(static_cast<float>(maxBX - minB) / (maxBY - minB));
+    if (L.n_roots < 1) return ORBX_ERR_TOO_SMALL;
+    if (L.n_roots > ORBX_MAX_ROOTS) return ORBX_ERR_UNSUPPORTED;
+    L.hX = static_cast<float>(maxBX - minB) / L.n_roots;
+    L.sel_cap = L.quota + 8 + 4 * L.n_roots;
+    L.sel_off = selOff;
+    selOff += L.sel_cap;
+    nodesCap = std::max(nodesCap, L.sel_cap);
+    L.scale = scale[l];
+    L.patch_size = (int)(31 * scale[l]);  // extractor.cc:840
+    // image planes
+    L.pstride = round_up(L.w + 2 * ORBX_EDGE, 64);
+    L.prows = L.h + 2 * ORBX_EDGE;
+    L.pyr_plane = (size_t)L.pstride * L.prows;
+    L.pyr_off = pyrOff;
+    pyrOff += L.pyr_plane * B;
+    L.bstride = round_up(L.w, 64);
+    L.blur_plane = (size_t)L.bstride * L.h;
+    L.blur_off = blurOff;
+    blurOff += L.blur_plane * B;
+    L.tiles_x = (L.w + 63) / 64;
+    L.tiles_y = (L.h + 31) / 32;
+    L.tile_first = tileFirst;
+    tileFirst += L.tiles_x * L.tiles_y;
+  }
+  hp.cells_per_frame = cellFirst;
+  hp.tiles_per_frame = tileFirst;
+  hp.cand_frame = candOff;
+  hp.flat_frame = flatOff;
+  hp.sel_frame = selOff;
+  hp.kp_cap = selOff;
+  hp.oct_nodes_cap = nodesCap;
+  hp.oct_cells_max = cellsMax;
+  maxKeypoints = selOff;
+  pyr_bytes = pyrOff;
+
+  if (hipSetDevice(device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  if (orbx::octree_set_lds_limit(hp) != 0) return ORBX_ERR_UNSUPPORTED;
+
+  planned = true;  // from here on freePlan() releases whatever was allocated
+  // resize tap tables
+  for (int l = 1; l < nl; ++l) {
+    std::vector<Tap> tx, ty;
+    build_taps(hp.lv[l - 1].w, hp.lv[l].w, true, tx);
+    build_taps(hp.lv[l - 1].h, hp.lv[l].h, false, ty);
+    Tap *dx = nullptr, *dy = nullptr;
+    HIP_TRY(hipMalloc((void**)&dx, tx.size() * sizeof(Tap)));
+    d_taps.push_back(dx);
+    HIP_TRY(hipMalloc((void**)&dy, ty.size() * sizeof(Tap)));
+    d_taps.push_back(dy);
+    HIP_TRY(hipMemcpy(dx, tx.data(), tx.size() * sizeof(Tap), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dy, ty.data(), ty.size() * sizeof(Tap), hipMemcpyHostToDevice));
+    hp.lv[l].xtab = dx;
+    hp.lv[l].ytab = dy;
+  }
+  HIP_TRY(hipMalloc((void**)&dp, sizeof(Plan)));
+  HIP_TRY(hipMemcpy(dp, &hp, sizeof(Plan), hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc((void**)&d_img, (size_t)B * W * H));
+  HIP_TRY(hipMalloc((void**)&d_pyr, pyrOff));
+  HIP_TRY(hipMalloc((void**)&d_blur, blurOff));
+  HIP_TRY(hipMalloc((void**)&d_cand, (size_t)B * hp.cand_frame * 4));
+  HIP_TRY(hipMalloc((void**)&d_cellCount, (size_t)B * hp.cells_per_frame * 4));
+  HIP_TRY(hipMalloc((void**)&d_flatA, (size_t)B * hp.flat_frame * 4));
+  HIP_TRY(hipMalloc((void**)&d_flatB, (size_t)B * hp.flat_frame * 4));
+  HIP_TRY(hipMalloc((void**)&d_sel, (size_t)B * hp.sel_frame * 4));
+  HIP_TRY(hipMalloc((void**)&d_selCount, (size_t)B * nl * 4));
+  HIP_TRY(hipMalloc((void**)&d_kps, (size_t)B * hp.kp_cap * 28));
+  HIP_TRY(hipMalloc((void**)&d_desc, (size_t)B * hp.kp_cap * 32));
+  HIP_TRY(hipMalloc((void**)&d_work, (size_t)B * hp.kp_cap * sizeof(WorkItem)));
+  HIP_TRY(hipMalloc((void**)&d_n, (size_t)B * 4));
+  HIP_TRY(hipMalloc((void**)&d_mono, (size_t)B * 4));
+  h_stage_bytes = std::max((size_t)W * H, (size_t)hp.kp_cap * 60 + 64);
+  HIP_TRY(hipHostMalloc((void**)&h_stage, h_stage_bytes, hipHostMallocDefault));
+  h_pyr.clear();
+  h_pyr_valid.assign(nl, 0);
+  return ORBX_OK;
+}
+
+int orbx_extractor::run(const uint8_t* d_images, int istride, size_t iframe, int nframes, int lap0,
+                        int lap1) {
+  hipStream_t s = stream;
+  const bool prof = profiling;
+  if (prof) HIP_TRY(hipEventRecord(ev[0], s));
+  orbx::launch_pyramid(hp, d_images, istride, iframe, d_pyr, nframes, s);
+  if (prof) HIP_TRY(hipEventRecord(ev[1], s));
+  orbx::launch_fast(hp, dp, d_pyr, d_cand, d_cellCount, nframes, s);
+  if (prof) HIP_TRY(hipEventRecord(ev[2], s));
+  orbx::launch_octree(hp, dp, d_cand, d_cellCount, d_flatA, d_flatB, d_sel, d_selCount, nframes, s);
+  if (prof) HIP_TRY(hipEventRecord(ev[3], s));
+  orbx::launch_assemble(hp, dp, d_sel, d_selCount, lap0, lap1, d_kps, d_work, d_n, d_mono, nframes, s);
+  if (prof) HIP_TRY(hipEventRecord(ev[4], s));
+  orbx::launch_blur(hp, dp, d_pyr, d_blur, nframes, s);
+  if (prof) HIP_TRY(hipEventRecord(ev[5], s));
+  orbx::launch_describe(hp, dp, d_pyr, d_blur, d_work, d_n, d_kps, d_desc, nframes, s);
+  if (prof) HIP_TRY(hipEventRecord(ev[6], s));
+  evValid = prof;
+  HIP_TRY(hipGetLastError());
+  lastFrames = nframes;
+  std::fill(h_pyr_valid.begin(), h_pyr_valid.end(), 0);
+  return ORBX_OK;
+}
+
+// ---------------------------------------------------------------------------
+extern "C" {
+
+const char* orbx_strerror(int status) {
+  switch (status) {
+    case ORBX_OK: return "ok";
+    case ORBX_ERR_EMPTY_IMAGE: return "empty image";
+    case ORBX_ERR_TOO_SMALL: return "image too small: a pyramid level has no 35-pixel detection cell";
+    case ORBX_ERR_CAPACITY: return "output capacity too small";
+    case ORBX_ERR_BAD_ARG: return "bad argument";
+    case ORBX_ERR_NO_DEVICE: return "no usable HIP device";
+    case ORBX_ERR_HIP: return "HIP runtime error";
+    case ORBX_ERR_UNSUPPORTED: return "parameters beyond what the kernels are sized for";
+    case ORBX_ERR_BATCH: return "more frames than the handle's max_batch";
+    default: return "unknown status";
+  }
+}
+
+int orbx_create(const orbx_params* p, orbx_extractor** out) {
+  if (!p || !out) return ORBX_ERR_BAD_ARG;
+  *out = nullptr;
+  if (p->nfeatures < 1 || p->nlevels < 1 || p->nlevels > ORBX_MAX_LEVELS || !(p->scale_factor > 1.0f) ||
+      p->max_batch < 1)
+    return ORBX_ERR_BAD_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return ORBX_ERR_NO_DEVICE;
+  if (p->device_id < 0 || p->device_id >= ndev) return ORBX_ERR_NO_DEVICE;
+  orbx_extractor* ex = new (std::nothrow) orbx_extractor();
+  if (!ex) return ORBX_ERR_BAD_ARG;
+  ex->prm = *p;
+  ex->device = p->device_id;
+  ex->buildTables();
+  if (hipSetDevice(ex->device) != hipSuccess ||
+      hipStreamCreateWithFlags(&ex->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ex;
+    return ORBX_ERR_NO_DEVICE;
+  }
+  for (int i = 0; i <= ORBX_NUM_STAGES; ++i)
+    if (hipEventCreate(&ex->ev[i]) != hipSuccess) { delete ex; return ORBX_ERR_NO_DEVICE; }
+  *out = ex;
+  return ORBX_OK;
+}
+
+void orbx_destroy(orbx_extractor* ex) {
+  if (!ex) return;
+  (void)hipSetDevice(ex->device);
+  ex->freePlan();
+  for (int i = 0; i <= ORBX_NUM_STAGES; ++i) if (ex->ev[i]) (void)hipEventDestroy(ex->ev[i]);
+  if (ex->stream) (void)hipStreamDestroy(ex->stream);
+  delete ex;
+}
+
+int orbx_get_tables(const orbx_extractor* ex, float* scale, float* inv_scale, float* sigma2,
+                    float* inv_sigma2, int32_t* features_per_level) {
+  if (!ex) return ORBX_ERR_BAD_ARG;
+  for (int i = 0; i < ex->prm.nlevels; ++i) {
+    if (scale) scale[i] = ex->scale[i];
+    if (inv_scale) inv_scale[i] = ex->invScale[i];
+    if (sigma2) sigma2[i] = ex->sigma2[i];
+    if (inv_sigma2) inv_sigma2[i] = ex->invSigma2[i];
+    if (features_per_level) features_per_level[i] = ex->quota[i];
+  }
+  return ORBX_OK;
+}
+
+int orbx_max_keypoints(const orbx_extractor* ex) {
+  if (!ex) return ORBX_ERR_BAD_ARG;
+  if (ex->planned) return ex->maxKeypoints;
+  int sum = 0;
+  for (int l = 0; l < ex->prm.nlevels; ++l) sum += ex->quota[l] + 8 + 4 * ORBX_MAX_ROOTS;
+  return sum;
+}
+
+void* orbx_stream(orbx_extractor* ex) { return ex ? (void*)ex->stream : nullptr; }
+
+int orbx_sync(orbx_extractor* ex) {
+  if (!ex) return ORBX_ERR_BAD_ARG;
+  if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  hipError_t e = hipStreamSynchronize(ex->stream);
+  if (e != hipSuccess) { ex->last_hip_error = e; return ORBX_ERR_HIP; }
+  return ORBX_OK;
+}
+
+int orbx_extract_batch_device(orbx_extractor* ex, int n_frames, const uint8_t* d_imgs, int width,
+                              int height, int stride, int lap0, int lap1) {
+  if (!ex) return ORBX_ERR_BAD_ARG;
+  if (!d_imgs || width <= 0 || height <= 0 || n_frames <= 0) return ORBX_ERR_EMPTY_IMAGE;
+  if (stride < width) return ORBX_ERR_BAD_ARG;
+  if (n_frames > ex->prm.max_batch) return ORBX_ERR_BATCH;
+  if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  int st = ex->ensurePlan(width, height);
+  if (st != ORBX_OK) { ex->freePlan(); return st; }
+  return ex->run(d_imgs, stride, (size_t)stride * height, n_frames, lap0, lap1);
+}
+
+int orbx_batch_results_device(orbx_extractor* ex, orbx_keypoint** d_kps, uint8_t** d_desc,
+                              int32_t** d_n, int32_t** d_mono, int* cap) {
+  if (!ex || !ex->planned) return ORBX_ERR_BAD_ARG;
+  if (d_kps) *d_kps = (orbx_keypoint*)ex->d_kps;
+  if (d_desc) *d_desc = ex->d_desc;
+  if (d_n) *d_n = ex->d_n;
+  if (d_mono) *d_mono = ex->d_mono;
+  if (cap) *cap = ex->hp.kp_cap;
+  return ORBX_OK;
+}
+
+int orbx_batch_download(orbx_extractor* ex, int frame, orbx_keypoint* kps, uint8_t* desc, int cap,
+                        int* n_out, int* mono_out) {
+  if (!ex || !ex->planned || frame < 0 || frame >= ex->lastFrames) return ORBX_ERR_BAD_ARG;
+  if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  hipStream_t s = ex->stream;
+  int nm[2];
+  {
+    hipError_t e;
+    e = hipMemcpyAsync(&nm[0], ex->d_n + frame, 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(&nm[1], ex->d_mono + frame, 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { ex->last_hip_error = e; return ORBX_ERR_HIP; }
+  }
+  const int n = nm[0];
+  if (n_out) *n_out = n;
+  if (mono_out) *mono_out = nm[1];
+  if (n > cap) return ORBX_ERR_CAPACITY;
+  if (n > 0) {
+    hipError_t e = hipSuccess;
+    const size_t base = (size_t)frame * ex->hp.kp_cap;
+    if (kps) e = hipMemcpyAsync(kps, ex->d_kps + base * 7, (size_t)n * 28, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && desc)
+      e = hipMemcpyAsync(desc, ex->d_desc + base * 32, (size_t)n * 32, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { ex->last_hip_error = e; return ORBX_ERR_HIP; }
+  }
+  return ORBX_OK;
+}
+
+int orbx_extract_batch(orbx_extractor* ex, int n_frames, const uint8_t* const* imgs, int width,
+                       int height, int stride, int lap0, int lap1, orbx_keypoint* kps,
+                       uint8_t* desc, int cap, int* n_out, int* mono_out) {
+  if (!ex) return ORBX_ERR_BAD_ARG;
+  if (!imgs || width <= 0 || height <= 0 || n_frames <= 0) return ORBX_ERR_EMPTY_IMAGE;
+  for (int f = 0; f < n_frames; ++f) if (!imgs[f]) return ORBX_ERR_EMPTY_IMAGE;
+  if (stride < width) return ORBX_ERR_BAD_ARG;
+  if (n_frames > ex->prm.max_batch) return ORBX_ERR_BATCH;
+  if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  int st = ex->ensurePlan(width, height);
+  if (st != ORBX_OK) { ex->freePlan(); return st; }
+  hipStream_t s = ex->stream;
+  for (int f = 0; f < n_frames; ++f) {
+    hipError_t e = hipMemcpy2DAsync(ex->d_img + (size_t)f * width * height, width, imgs[f], stride,
+                                    width, height, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) { ex->last_hip_error = e; return ORBX_ERR_HIP; }
+  }
+  st = ex->run(ex->d_img, width, (size_t)width * height, n_frames, lap0, lap1);
+  if (st != ORBX_OK) return st;
+  int worst = ORBX_OK;
+  for (int f = 0; f < n_frames; ++f) {
+    int n = 0, mono = 0;
+    st = orbx_batch_download(ex, f, kps ? kps + (size_t)f * cap : nullptr,
+                             desc ? desc + (size_t)f * cap * 32 : nullptr, cap, &n, &mono);
+    if (n_out) n_out[f] = n;
+    if (mono_out) mono_out[f] = mono;
+    if (st != ORBX_OK) worst = st;
+  }
+  return worst;
+}
+
+int orbx_extract(orbx_extractor* ex, const uint8_t* img, int width, int height, int stride, int lap0,
+                 int lap1, orbx_keypoint* kps, uint8_t* desc, int cap, int* n_out, int* mono_out) {
+  if (n_out) *n_out = 0;
+  if (mono_out) *mono_out = -1;
+  if (!ex) return ORBX_ERR_BAD_ARG;
+  if (!img || width <= 0 || height <= 0) return ORBX_ERR_EMPTY_IMAGE;
+  const uint8_t* one[1] = {img};
+  int n = 0, mono = -1;
+  int st = orbx_extract_batch(ex, 1, one, width, height, stride, lap0, lap1, kps, desc, cap, &n, &mono);
+  if (n_out) *n_out = n;
+  if (mono_out) *mono_out = mono;
+  return st;
+}
+
+int orbx_level_dims(orbx_extractor* ex, int level, int* width, int* height, int* stride) {
+  if (!ex || !ex->planned || level < 0 || level >= ex->hp.nlevels) return ORBX_ERR_BAD_ARG;
+  if (width) *width = ex->hp.lv[level].w;
+  if (height) *height = ex->hp.lv[level].h;
+  if (stride) *stride = ex->hp.lv[level].pstride;
+  return ORBX_OK;
+}
+
+int orbx_debug_level_padded(orbx_extractor* ex, int frame, int level, uint8_t* dst) {
+  if (!ex || !ex->planned || !dst || level < 0 || level >= ex->hp.nlevels || frame < 0 ||
+      frame >= ex->lastFrames)
+    return ORBX_ERR_BAD_ARG;
+  if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  const LevelDesc& L = ex->hp.lv[level];
+  {
+    hipError_t e = hipStreamSynchronize(ex->stream);
+    if (e == hipSuccess)
+      e = hipMemcpy(dst, ex->d_pyr + L.pyr_off + (size_t)frame * L.pyr_plane, L.pyr_plane,
+                    hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { ex->last_hip_error = e; return ORBX_ERR_HIP; }
+  }
+  return ORBX_OK;
+}
+
+int orbx_pyramid(orbx_extractor* ex, int level, const uint8_t** padded, int* width, int* height,
+                 int* stride) {
+  if (!ex || !ex->planned || !padded || level < 0 || level >= ex->hp.nlevels || ex->lastFrames < 1)
+    return ORBX_ERR_BAD_ARG;
+  // host mirror of frame 0's pyramid: all levels back to back
+  size_t total = 0, off = 0;
+  for (int l = 0; l < ex->hp.nlevels; ++l) {
+    if (l == level) off = total;
+    total += ex->hp.lv[l].pyr_plane;
+  }
+  if (ex->h_pyr.size() != total) ex->h_pyr.assign(total, 0);
+  if (!ex->h_pyr_valid[level]) {
+    int st = orbx_debug_level_padded(ex, 0, level, ex->h_pyr.data() + off);
+    if (st != ORBX_OK) return st;
+    ex->h_pyr_valid[level] = 1;
+  }
+  *padded = ex->h_pyr.data() + off;
+  return orbx_level_dims(ex, level, width, height, stride);
+}
+
+int orbx_debug_level_candidates(orbx_extractor* ex, int frame, int level, int32_t* xys, int cap,
+                                int* n_out) {
+  if (!ex || !ex->planned || level < 0 || level >= ex->hp.nlevels || frame < 0 ||
+      frame >= ex->lastFrames || !n_out)
+    return ORBX_ERR_BAD_ARG;
+  if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  const LevelDesc& L = ex->hp.lv[level];
+  const int nc = L.ncx * L.ncy;
+  std::vector<int> counts(nc);
+  std::vector<uint32_t> seg((size_t)nc * L.cand_cap_cell);
+  hipError_t e = hipStreamSynchronize(ex->stream);
+  if (e == hipSuccess)
+    e = hipMemcpy(counts.data(), ex->d_cellCount + (size_t)frame * ex->hp.cells_per_frame + L.cell_first,
+                  (size_t)nc * 4, hipMemcpyDeviceToHost);
+  if (e == hipSuccess)
+    e = hipMemcpy(seg.data(), ex->d_cand + (size_t)frame * ex->hp.cand_frame + L.cand_off,
+                  seg.size() * 4, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) { ex->last_hip_error = e; return ORBX_ERR_HIP; }
+  int n = 0;
+  for (int c = 0; c < nc; ++c)
+    for (int k = 0; k < counts[c]; ++k, ++n)
+      if (n < cap && xys) {
+        const uint32_t key = seg[(size_t)c * L.cand_cap_cell + k];
+        xys[3 * n] = key & 0xFFF; xys[3 * n + 1] = (key >> 12) & 0xFFF; xys[3 * n + 2] = key >> 24;
+      }
+  *n_out = n;
+  return n > cap ? ORBX_ERR_CAPACITY : ORBX_OK;
+}
+
+int orbx_debug_level_selected(orbx_extractor* ex, int frame, int level, int32_t* xys, int cap,
+                              int* n_out) {
+  if (!ex || !ex->planned || level < 0 || level >= ex->hp.nlevels || frame < 0 ||
+      frame >= ex->lastFrames || !n_out)
+    return ORBX_ERR_BAD_ARG;
+  if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  const LevelDesc& L = ex->hp.lv[level];
+  int n = 0;
+  std::vector<uint32_t> keys(L.sel_cap);
+  hipError_t e = hipStreamSynchronize(ex->stream);
+  if (e == hipSuccess)
+    e = hipMemcpy(&n, ex->d_selCount + (size_t)frame * ex->hp.nlevels + level, 4, hipMemcpyDeviceToHost);
+  if (e == hipSuccess)
+    e = hipMemcpy(keys.data(), ex->d_sel + (size_t)frame * ex->hp.sel_frame + L.sel_off,
+                  keys.size() * 4, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) { ex->last_hip_error = e; return ORBX_ERR_HIP; }
+  for (int i = 0; i < n && i < cap && xys; ++i) {
+    xys[3 * i] = keys[i] & 0xFFF; xys[3 * i + 1] = (keys[i] >> 12) & 0xFFF; xys[3 * i + 2] = keys[i] >> 24;
+  }
+  *n_out = n;
+  return n > cap ? ORBX_ERR_CAPACITY : ORBX_OK;
+}
+
+int orbx_debug_level_blurred(orbx_extractor* ex, int frame, int level, uint8_t* dst) {
+  if (!ex || !ex->planned || !dst || level < 0 || level >= ex->hp.nlevels || frame < 0 ||
+      frame >= ex->lastFrames)
+    return ORBX_ERR_BAD_ARG;
+  if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  const LevelDesc& L = ex->hp.lv[level];
+  hipError_t e = hipStreamSynchronize(ex->stream);
+  if (e == hipSuccess)
+    e = hipMemcpy2D(dst, L.w, ex->d_blur + L.blur_off + (size_t)frame * L.blur_plane, L.bstride, L.w,
+                    L.h, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) { ex->last_hip_error = e; return ORBX_ERR_HIP; }
+  return ORBX_OK;
+}
+
+int orbx_set_profiling(orbx_extractor* ex, int enabled) {
+  if (!ex) return ORBX_ERR_BAD_ARG;
+  ex->profiling = enabled != 0;
+  ex->evValid = false;
+  return ORBX_OK;
+}
+
+int orbx_stage_times(orbx_extractor* ex, float* ms, int n) {
+  if (!ex || !ms || n < ORBX_NUM_STAGES || !ex->evValid) return ORBX_ERR_BAD_ARG;
+  if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  hipError_t e = hipEventSynchronize(ex->ev[ORBX_NUM_STAGES]);
+  for (int i = 0; i < ORBX_NUM_STAGES && e == hipSuccess; ++i)
+    e = hipEventElapsedTime(&ms[i], ex->ev[i], ex->ev[i + 1]);
+  if (e != hipSuccess) { ex->last_hip_error = e; return ORBX_ERR_HIP; }
+  return ORBX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Synthetic textured frame: mid-gray, 400 random axis-aligned rectangles
+// (side 6..96, gray 0..255), +-6 uniform noise, one 3x3 box blur (REFLECT_101
+// borders).  PCG32 (XSH-RR), stream constant 54.
+// ---------------------------------------------------------------------------
+namespace {
+struct Pcg32 {
+  uint64_t state, inc;
+  explicit Pcg32(uint64_t seed) {
+    state = 0; inc = (54u << 1) | 1u;
+    next(); state += seed; next();
+  }
+  uint32_t next() {
+    uint64_t old = state;
+    state = old * 6364136223846793005ULL + inc;
+    uint32_t xs = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+    uint32_t rot = (uint32_t)(old >> 59u);
+    return (xs >> rot) | (xs << ((32 - rot) & 31));
+  }
+  uint32_t below(uint32_t n) { return (uint32_t)(((uint64_t)next() * n) >> 32); }
+};
+}  // namespace
+
+int orbx_synth_frame(uint32_t seed, int width, int height, int stride, uint8_t* dst) {
+  if (!dst || width < 8 || height < 8 || stride < width) return ORBX_ERR_BAD_ARG;
+  Pcg32 rng(0x0B5EEDull ^ (uint64_t)seed);
+  std::vector<int> img((size_t)width * height, 128);
+  for (int r = 0; r < 400; ++r) {
+    int rw = 6 + (int)rng.below(91), rh = 6 + (int)rng.below(91);
+    int x0 = (int)rng.below((uint32_t)width) - rw / 2, y0 = (int)rng.below((uint32_t)height) - rh / 2;
+    int g = (int)rng.below(256);
+    for (int y = std::max(y0, 0); y < std::min(y0 + rh, height); ++y)
+      for (int x = std::max(x0, 0); x < std::min(x0 + rw, width); ++x) img[(size_t)y * width + x] = g;
+  }
+  for (size_t i = 0; i < img.size(); ++i) {
+    int v = img[i] + (int)rng.below(13) - 6;
+    img[i] = std::min(std::max(v, 0), 255);
+  }
+  for (int y = 0; y < height; ++y)
+    for (int x = 0; x < width; ++x) {
+      int s = 0;
+      for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx)
+          s += img[(size_t)reflect101(y + dy, height) * width + reflect101(x + dx, width)];
+      dst[(size_t)y * stride + x] = (uint8_t)((s + 4) / 9);
+    }
+  return ORBX_OK;
+}
+
+}  // extern "C"

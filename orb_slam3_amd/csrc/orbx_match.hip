@@ -1,0 +1,286 @@
+// Hamming matching on 256-bit ORB descriptors (gfx950).
+//
+//   orbx_hamming            ORBmatcher::DescriptorDistance      core/lib/ORB/matcher.cc:1961-1975
+//   k_knn2 / k_top2_merge   BFMatcher(NORM_HAMMING).knnMatch(.., 2) as used at core/src/Frame.cc:1177
+//   k_stereo_band           descriptor search of Frame::ComputeStereoMatches  core/src/Frame.cc:840-908
+//
+// The brute-force kernel is VALU-bound by design: per (query, train) pair it
+// spends 8 v_xor_b32 + 8 accumulating v_bcnt_u32_b32 and 4 instructions of
+// top-2 upkeep.  Every lane keeps QPL queries in registers; the train
+// descriptor of the current step is the same for the whole wave, so it is
+// fetched through wave-uniform (scalar) loads and costs no vector memory or
+// LDS traffic at all.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "../../include/orbx.h"
+
+namespace orbx {
+
+#define KNN_QPL 2          // queries per lane
+#define KNN_BLOCK 256
+#define KNN_IDX_BITS 22    // train rows per scan segment <= 2^22
+
+// Candidates are ranked by the 32-bit word (distance << 22 | local train
+// index): its unsigned order is exactly (distance, index) ascending, the
+// order in which cv::batchDistance keeps neighbours (strict comparisons, the
+// earliest index wins a tie).
+__global__ __launch_bounds__(KNN_BLOCK) void k_knn2(const uint32_t* __restrict__ q, int nq,
+                                                   const uint32_t* __restrict__ t, long long nt,
+                                                   int seg_len, uint32_t index_offset,
+                                                   uint32_t* __restrict__ out_idx,
+                                                   uint16_t* __restrict__ out_dist) {
+  const int tid = threadIdx.x;
+  const int seg = blockIdx.y;
+  const long long t0 = (long long)seg * seg_len;
+  const int len = (int)min((long long)seg_len, nt - t0);
+  uint32_t qa[KNN_QPL][8];
+  uint32_t k0[KNN_QPL], k1[KNN_QPL];
+#pragma unroll
+  for (int u = 0; u < KNN_QPL; ++u) {
+    const int qi = (blockIdx.x * KNN_QPL + u) * KNN_BLOCK + tid;
+    const uint4* qp = (const uint4*)(q + (size_t)min(qi, nq - 1) * 8);
+    const uint4 a = qp[0], b = qp[1];
+    qa[u][0] = a.x; qa[u][1] = a.y; qa[u][2] = a.z; qa[u][3] = a.w;
+    qa[u][4] = b.x; qa[u][5] = b.y; qa[u][6] = b.z; qa[u][7] = b.w;
+    k0[u] = 0xFFFFFFFFu;
+    k1[u] = 0xFFFFFFFFu;
+  }
+  const uint32_t* tp = t + (size_t)t0 * 8;
+#pragma unroll 4
+  for (int j = 0; j < len; ++j) {
+    uint32_t tv[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) tv[w] = tp[(size_t)j * 8 + w];  // wave-uniform -> scalar loads
+#pragma unroll
+    for (int u = 0; u < KNN_QPL; ++u) {
+      uint32_t d = 0;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) d += __builtin_popcount(qa[u][w] ^ tv[w]);
+      const uint32_t key = (d << KNN_IDX_BITS) | (uint32_t)j;
+      const uint32_t hi = max(k0[u], key);
+      k0[u] = min(k0[u], key);
+      k1[u] = min(k1[u], hi);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < KNN_QPL; ++u) {
+    const int qi = (blockIdx.x * KNN_QPL + u) * KNN_BLOCK + tid;
+    if (qi < nq) {
+      const size_t o = ((size_t)seg * nq + qi) * 2;
+      const uint32_t base = index_offset + (uint32_t)t0;
+      const uint32_t mask = (1u << KNN_IDX_BITS) - 1u;
+      out_idx[o] = k0[u] == 0xFFFFFFFFu ? 0xFFFFFFFFu : base + (k0[u] & mask);
+      out_idx[o + 1] = k1[u] == 0xFFFFFFFFu ? 0xFFFFFFFFu : base + (k1[u] & mask);
+      out_dist[o] = k0[u] == 0xFFFFFFFFu ? (uint16_t)0xFFFF : (uint16_t)(k0[u] >> KNN_IDX_BITS);
+      out_dist[o + 1] = k1[u] == 0xFFFFFFFFu ? (uint16_t)0xFFFF : (uint16_t)(k1[u] >> KNN_IDX_BITS);
+    }
+  }
+}
+
+// Merge partial 2-NN lists [part][nq][2] by (distance, index); parts are
+// visited in order and comparisons are strict, so equal (distance, index)
+// pairs cannot reorder and the earliest index wins a distance tie.
+__global__ __launch_bounds__(256) void k_top2_merge(const uint32_t* __restrict__ idx_parts,
+                                                    const uint16_t* __restrict__ dist_parts,
+                                                    int nparts, int nq, uint32_t* __restrict__ idx,
+                                                    uint16_t* __restrict__ dist) {
+  const int qi = blockIdx.x * 256 + threadIdx.x;
+  if (qi >= nq) return;
+  unsigned long long b0 = ~0ull, b1 = ~0ull;
+  for (int p = 0; p < nparts; ++p) {
+    const size_t o = ((size_t)p * nq + qi) * 2;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const unsigned long long key = ((unsigned long long)dist_parts[o + e] << 32) | idx_parts[o + e];
+      const unsigned long long hi = key > b0 ? key : b0;
+      b0 = key < b0 ? key : b0;
+      b1 = hi < b1 ? hi : b1;
+    }
+  }
+  idx[2 * (size_t)qi] = (uint32_t)b0;
+  idx[2 * (size_t)qi + 1] = (uint32_t)b1;
+  dist[2 * (size_t)qi] = (uint16_t)(b0 >> 32);
+  dist[2 * (size_t)qi + 1] = (uint16_t)(b1 >> 32);
+}
+
+// One lane per left keypoint; right keypoints are visited in ascending index,
+// so the first minimum wins as in the reference's row-bucket order.
+struct KP { float x, y, size, angle, response; int octave, class_id; };
+
+__global__ __launch_bounds__(256) void k_stereo_band(const KP* __restrict__ kl,
+                                                     const uint32_t* __restrict__ dl, int nl,
+                                                     const KP* __restrict__ kr,
+                                                     const uint32_t* __restrict__ dr, int nr,
+                                                     const float* __restrict__ scaleFactors,
+                                                     int nRows, float minD, float maxD,
+                                                     int* __restrict__ bestIdx,
+                                                     int* __restrict__ bestDist) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nl) return;
+  const KP L = kl[i];
+  uint32_t a[8];
+#pragma unroll
+  for (int w = 0; w < 8; ++w) a[w] = dl[(size_t)i * 8 + w];
+  const int row = (int)L.y;
+  const float minU = __fsub_rn(L.x, maxD), maxU = __fsub_rn(L.x, minD);
+  int best = 100, bi = -1;
+  const bool live = row >= 0 && row < nRows && !(maxU < 0.f);
+  if (live) {
+    for (int j = 0; j < nr; ++j) {
+      const KP R = kr[j];
+      const float r = __fmul_rn(2.0f, scaleFactors[R.octave]);
+      const int maxr = (int)ceilf(__fadd_rn(R.y, r));
+      const int minr = (int)floorf(__fsub_rn(R.y, r));
+      if (row < minr || row > maxr) continue;
+      if (R.octave < L.octave - 1 || R.octave > L.octave + 1) continue;
+      if (!(R.x >= minU && R.x <= maxU)) continue;
+      int d = 0;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) d += __builtin_popcount(a[w] ^ dr[(size_t)j * 8 + w]);
+      if (d < best) { best = d; bi = j; }
+    }
+  }
+  bestIdx[i] = bi;
+  bestDist[i] = best;
+}
+
+}  // namespace orbx
+
+namespace {
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
+};
+}  // namespace
+
+extern "C" {
+
+int orbx_hamming(const uint8_t* a, const uint8_t* b) {
+  int d = 0;
+  for (int i = 0; i < 8; ++i) {
+    uint32_t x, y;
+    __builtin_memcpy(&x, a + 4 * i, 4);
+    __builtin_memcpy(&y, b + 4 * i, 4);
+    d += __builtin_popcount(x ^ y);
+  }
+  return d;
+}
+
+// Partial results for nsegs train segments need nsegs*nq*2 entries of scratch.
+static int knn2_launch(const uint8_t* d_q, int nq, const uint8_t* d_t, int64_t nt,
+                       uint32_t index_offset, uint32_t* d_idx, uint16_t* d_dist, hipStream_t s) {
+  if (nq <= 0) return ORBX_OK;
+  const int qblocks = (nq + KNN_QPL * KNN_BLOCK - 1) / (KNN_QPL * KNN_BLOCK);
+  // enough segments to occupy the chip when there are few query blocks
+  long long segs = 1;
+  if (nt > 0) {
+    const long long want = (2048 + qblocks - 1) / qblocks;
+    const long long minLen = 512;
+    segs = std::max(1LL, std::min(want, (long long)((nt + minLen - 1) / minLen)));
+    const long long maxLen = 1LL << KNN_IDX_BITS;
+    segs = std::max(segs, (long long)((nt + maxLen - 1) / maxLen));
+  }
+  const int seg_len = nt > 0 ? (int)((nt + segs - 1) / segs) : 1;
+  segs = nt > 0 ? (nt + seg_len - 1) / seg_len : 1;
+  if (segs > 65535) return ORBX_ERR_UNSUPPORTED;
+  if (segs == 1) {
+    hipLaunchKernelGGL(orbx::k_knn2, dim3(qblocks, 1), dim3(KNN_BLOCK), 0, s, (const uint32_t*)d_q, nq,
+                       (const uint32_t*)d_t, (long long)nt, seg_len, index_offset, d_idx, d_dist);
+  } else {
+    uint32_t* pidx = nullptr;
+    uint16_t* pdist = nullptr;
+    if (hipMallocAsync((void**)&pidx, (size_t)segs * nq * 2 * 4, s) != hipSuccess) return ORBX_ERR_HIP;
+    if (hipMallocAsync((void**)&pdist, (size_t)segs * nq * 2 * 2, s) != hipSuccess) {
+      (void)hipFreeAsync(pidx, s);
+      return ORBX_ERR_HIP;
+    }
+    hipLaunchKernelGGL(orbx::k_knn2, dim3(qblocks, (unsigned)segs), dim3(KNN_BLOCK), 0, s,
+                       (const uint32_t*)d_q, nq, (const uint32_t*)d_t, (long long)nt, seg_len,
+                       index_offset, pidx, pdist);
+    hipLaunchKernelGGL(orbx::k_top2_merge, dim3((nq + 255) / 256), dim3(256), 0, s, pidx, pdist,
+                       (int)segs, nq, d_idx, d_dist);
+    (void)hipFreeAsync(pidx, s);
+    (void)hipFreeAsync(pdist, s);
+  }
+  return hipGetLastError() == hipSuccess ? ORBX_OK : ORBX_ERR_HIP;
+}
+
+int orbx_knn2_device(const uint8_t* d_q, int nq, const uint8_t* d_t, int64_t nt, uint32_t index_offset,
+                     uint32_t* d_idx, uint16_t* d_dist, void* stream) {
+  if (nq < 0 || nt < 0 || (nq > 0 && (!d_q || !d_idx || !d_dist)) || (nt > 0 && !d_t))
+    return ORBX_ERR_BAD_ARG;
+  if (((uintptr_t)d_q | (uintptr_t)d_t) & 15) return ORBX_ERR_BAD_ARG;  // rows are read as 16-byte words
+  return knn2_launch(d_q, nq, d_t, nt, index_offset, d_idx, d_dist, (hipStream_t)stream);
+}
+
+int orbx_top2_merge_device(const uint32_t* d_idx_parts, const uint16_t* d_dist_parts, int nparts, int nq,
+                           uint32_t* d_idx, uint16_t* d_dist, void* stream) {
+  if (nparts < 1 || nq < 0 || (nq > 0 && (!d_idx_parts || !d_dist_parts || !d_idx || !d_dist)))
+    return ORBX_ERR_BAD_ARG;
+  if (nq == 0) return ORBX_OK;
+  hipLaunchKernelGGL(orbx::k_top2_merge, dim3((nq + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     d_idx_parts, d_dist_parts, nparts, nq, d_idx, d_dist);
+  return hipGetLastError() == hipSuccess ? ORBX_OK : ORBX_ERR_HIP;
+}
+
+int orbx_knn2(int device_id, const uint8_t* q, int nq, const uint8_t* t, int64_t nt, uint32_t* idx,
+              uint16_t* dist) {
+  if (nq < 0 || nt < 0 || (nq > 0 && (!q || !idx || !dist)) || (nt > 0 && !t)) return ORBX_ERR_BAD_ARG;
+  if (nq == 0) return ORBX_OK;
+  if (hipSetDevice(device_id) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  DevBuf dq, dt, di, dd;
+  if (dq.alloc((size_t)nq * 32) != hipSuccess || dt.alloc((size_t)nt * 32) != hipSuccess ||
+      di.alloc((size_t)nq * 8) != hipSuccess || dd.alloc((size_t)nq * 4) != hipSuccess)
+    return ORBX_ERR_HIP;
+  if (hipMemcpy(dq.p, q, (size_t)nq * 32, hipMemcpyHostToDevice) != hipSuccess) return ORBX_ERR_HIP;
+  if (nt > 0 && hipMemcpy(dt.p, t, (size_t)nt * 32, hipMemcpyHostToDevice) != hipSuccess)
+    return ORBX_ERR_HIP;
+  int st = knn2_launch((const uint8_t*)dq.p, nq, (const uint8_t*)dt.p, nt, 0, (uint32_t*)di.p,
+                       (uint16_t*)dd.p, nullptr);
+  if (st != ORBX_OK) return st;
+  if (hipDeviceSynchronize() != hipSuccess) return ORBX_ERR_HIP;
+  if (hipMemcpy(idx, di.p, (size_t)nq * 8, hipMemcpyDeviceToHost) != hipSuccess) return ORBX_ERR_HIP;
+  if (hipMemcpy(dist, dd.p, (size_t)nq * 4, hipMemcpyDeviceToHost) != hipSuccess) return ORBX_ERR_HIP;
+  return ORBX_OK;
+}
+
+int orbx_stereo_band_match(int device_id, const orbx_keypoint* kps_l, const uint8_t* desc_l, int n_l,
+                           const orbx_keypoint* kps_r, const uint8_t* desc_r, int n_r,
+                           const float* scale_factors, int nlevels, int n_rows, float min_d,
+                           float max_d, int32_t* best_idx, int32_t* best_dist) {
+  if (n_l < 0 || n_r < 0 || nlevels < 1 || !scale_factors || (n_l > 0 && (!kps_l || !desc_l || !best_idx || !best_dist)) ||
+      (n_r > 0 && (!kps_r || !desc_r)))
+    return ORBX_ERR_BAD_ARG;
+  if (n_l == 0) return ORBX_OK;
+  for (int j = 0; j < n_r; ++j)
+    if (kps_r[j].octave < 0 || kps_r[j].octave >= nlevels) return ORBX_ERR_BAD_ARG;
+  if (hipSetDevice(device_id) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  DevBuf kl, dl, kr, dr, sf, bi, bd;
+  if (kl.alloc((size_t)n_l * 28) != hipSuccess || dl.alloc((size_t)n_l * 32) != hipSuccess ||
+      kr.alloc((size_t)n_r * 28) != hipSuccess || dr.alloc((size_t)n_r * 32) != hipSuccess ||
+      sf.alloc((size_t)nlevels * 4) != hipSuccess || bi.alloc((size_t)n_l * 4) != hipSuccess ||
+      bd.alloc((size_t)n_l * 4) != hipSuccess)
+    return ORBX_ERR_HIP;
+  hipError_t e = hipMemcpy(kl.p, kps_l, (size_t)n_l * 28, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dl.p, desc_l, (size_t)n_l * 32, hipMemcpyHostToDevice);
+  if (e == hipSuccess && n_r) e = hipMemcpy(kr.p, kps_r, (size_t)n_r * 28, hipMemcpyHostToDevice);
+  if (e == hipSuccess && n_r) e = hipMemcpy(dr.p, desc_r, (size_t)n_r * 32, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(sf.p, scale_factors, (size_t)nlevels * 4, hipMemcpyHostToDevice);
+  if (e != hipSuccess) return ORBX_ERR_HIP;
+  hipLaunchKernelGGL(orbx::k_stereo_band, dim3((n_l + 255) / 256), dim3(256), 0, nullptr,
+                     (const orbx::KP*)kl.p, (const uint32_t*)dl.p, n_l, (const orbx::KP*)kr.p,
+                     (const uint32_t*)dr.p, n_r, (const float*)sf.p, n_rows, min_d, max_d, (int*)bi.p,
+                     (int*)bd.p);
+  e = hipGetLastError();
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(best_idx, bi.p, (size_t)n_l * 4, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(best_dist, bd.p, (size_t)n_l * 4, hipMemcpyDeviceToHost);
+  return e == hipSuccess ? ORBX_OK : ORBX_ERR_HIP;
+}
+
+}  // extern "C"

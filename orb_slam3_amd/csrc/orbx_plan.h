@@ -1,0 +1,80 @@
+// Host/device shared description of one extraction plan: everything the
+// kernels need to know about an (image size, extractor parameters, batch
+// capacity) combination.  Built once on the host (orbx_api.hip), copied to
+// device memory, and read through wave-uniform loads.
+#ifndef ORBX_PLAN_H_
+#define ORBX_PLAN_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#define ORBX_MAX_LEVELS 16
+#define ORBX_EDGE 19          /* EDGE_THRESHOLD, core/lib/ORB/extractor.cc:73 */
+#define ORBX_DET_ORG 16       /* minBorder = EDGE_THRESHOLD - 3, extractor.cc:754 */
+#define ORBX_CELL_MAX 72      /* cell side never exceeds 70 (= 2*35) pixels */
+#define ORBX_MAX_ROOTS 16
+
+namespace orbx {
+
+// Resize tap table entry, indexed by PADDED destination coordinate (the
+// REFLECT_101 border mapping is folded in): two source indices and the two
+// 11-bit fixed-point weights of cv::resize INTER_LINEAR.
+struct Tap {
+  uint16_t s0, s1;
+  int16_t w0, w1;
+};
+
+struct LevelDesc {
+  int w, h;              // level image size
+  int pstride, prows;    // padded plane: row stride (bytes, multiple of 64), rows = h + 38
+  size_t pyr_off;        // byte offset of frame 0's padded plane in the pyramid buffer
+  size_t pyr_plane;      // bytes per frame
+  int bstride;           // blurred image row stride (multiple of 64)
+  size_t blur_off, blur_plane;
+  // detection grid (extractor.cc:762-768); only cells with a non-empty domain
+  int ncx, ncy, wCell, hCell;
+  int cell_first;        // first cell of this level in the per-frame numbering
+  int cand_cap_cell;     // candidate slots per cell = ceil(wCell/2)*ceil(hCell/2)
+  uint32_t cand_off;     // uint32 offset of this level's cell segments inside a frame
+  uint32_t flat_off;     // uint32 offset of this level's flat key area inside a frame
+  uint32_t flat_cap;
+  // blur tiling
+  int tiles_x, tiles_y, tile_first;
+  // quadtree (extractor.cc:549-568)
+  int quota;             // mnFeaturesPerLevel[level]
+  int n_roots;
+  float hX;
+  int sel_cap, sel_off;  // selected-key slots for this level inside a frame
+  float scale;           // mvScaleFactor[level]
+  int patch_size;        // (int)(31 * scale)
+  const Tap* xtab;       // [w + 38]
+  const Tap* ytab;       // [h + 38]
+};
+
+struct Plan {
+  int nlevels, W, H;
+  int ini_th, min_th;
+  int max_batch;
+  int cells_per_frame;
+  int tiles_per_frame;
+  uint32_t cand_frame;   // uint32 per frame in the per-cell candidate buffer
+  uint32_t flat_frame;   // uint32 per frame in each flat key buffer
+  int sel_frame;         // selected-key slots per frame (all levels)
+  int kp_cap;            // keypoint slots per frame in the outputs (= sel_frame)
+  int oct_nodes_cap;     // quadtree node slots (max over levels)
+  int oct_cells_max;     // max cells in one level
+  int umax[16];          // circular patch row half-widths (extractor.cc:448-462)
+  LevelDesc lv[ORBX_MAX_LEVELS];
+};
+
+// One unit of work for the orientation + descriptor kernel.
+struct WorkItem {
+  int level;
+  uint32_t xy;   // x | y << 16, level coordinates
+  int dst;       // output slot inside the frame
+  int pad;
+};
+
+}  // namespace orbx
+
+#endif

@@ -1,0 +1,189 @@
+"""ctypes wrapper of the CPU oracle (oracle/liborb_oracle.so).  Test infrastructure only."""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KP = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+               ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(os.path.join(ROOT, "oracle", "liborb_oracle.so"))
+        L.orc_create.restype = C.c_void_p
+        L.orc_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        L.orc_destroy.argtypes = [C.c_void_p]
+        L.orc_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+        L.orc_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_level_dims.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_level_padded.restype = C.c_void_p
+        L.orc_level_padded.argtypes = [C.c_void_p, C.c_int]
+        L.orc_level_candidates.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.orc_level_keys.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_level_blurred.restype = C.c_void_p
+        L.orc_level_blurred.argtypes = [C.c_void_p, C.c_int]
+        L.orc_cv_round.argtypes = [C.c_float]
+        L.orc_fast_atan2.restype = C.c_float
+        L.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.orc_resize_linear_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                           C.c_int, C.c_int]
+        L.orc_gauss7.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_fast.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_octree.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_void_p, C.c_int]
+        L.orc_sort_sized_nodes.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_hamming.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_knn2.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        L.orc_stereo_band_match.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                            C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float,
+                                            C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+class Extractor:
+    def __init__(self, nfeatures, scale, nlevels, ini, mn):
+        self.h = lib().orc_create(nfeatures, scale, nlevels, ini, mn)
+        assert self.h
+        self.nlevels = nlevels
+        self.nfeatures = nfeatures
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_destroy(self.h)
+            self.h = None
+
+    def tables(self):
+        nl = self.nlevels
+        sc, inv, s2, is2 = (np.zeros(nl, np.float32) for _ in range(4))
+        q = np.zeros(nl, np.int32)
+        um = np.zeros(16, np.int32)
+        lib().orc_tables(self.h, _p(sc), _p(inv), _p(s2), _p(is2), _p(q), _p(um))
+        return dict(scale=sc, inv=inv, sigma2=s2, inv_sigma2=is2, quota=q, umax=um)
+
+    def extract(self, img, lap=(0, 0), cap=None):
+        img = np.ascontiguousarray(img)
+        h, w = img.shape
+        cap = cap or (self.nfeatures * 2 + 256)
+        kps = np.zeros(cap, KP)
+        desc = np.zeros((cap, 32), np.uint8)
+        n, mono = C.c_int(), C.c_int()
+        st = lib().orc_extract(self.h, _p(img), w, h, img.strides[0], lap[0], lap[1], _p(kps), _p(desc),
+                               cap, C.byref(n), C.byref(mono))
+        if st == -3:
+            return self.extract(img, lap, n.value)
+        return st, mono.value, kps[:n.value].copy(), desc[:n.value].copy()
+
+    def level_dims(self, l):
+        w, h, s = C.c_int(), C.c_int(), C.c_int()
+        assert lib().orc_level_dims(self.h, l, C.byref(w), C.byref(h), C.byref(s)) == 0
+        return w.value, h.value, s.value
+
+    def padded(self, l):
+        w, h, s = self.level_dims(l)
+        p = lib().orc_level_padded(self.h, l)
+        buf = (C.c_uint8 * ((h + 38) * s)).from_address(p)
+        return np.frombuffer(buf, np.uint8).reshape(h + 38, s).copy()
+
+    def candidates(self, l):
+        n = lib().orc_level_candidates(self.h, l, None, 0)
+        out = np.zeros((max(n, 1), 3), np.int32)
+        lib().orc_level_candidates(self.h, l, _p(out), n)
+        return out[:n]
+
+    def keys(self, l):
+        n = lib().orc_level_keys(self.h, l, None, None, 0)
+        k = np.zeros(max(n, 1), KP)
+        m = np.zeros((max(n, 1), 2), np.int32)
+        lib().orc_level_keys(self.h, l, _p(k), _p(m), n)
+        return k[:n], m[:n]
+
+    def blurred(self, l):
+        w, h, _ = self.level_dims(l)
+        p = lib().orc_level_blurred(self.h, l)
+        if not p:
+            return None
+        buf = (C.c_uint8 * (w * h)).from_address(p)
+        return np.frombuffer(buf, np.uint8).reshape(h, w).copy()
+
+
+def cv_round(v):
+    return lib().orc_cv_round(float(v))
+
+
+def fast_atan2(y, x):
+    return lib().orc_fast_atan2(float(y), float(x))
+
+
+def resize(src, dw, dh):
+    src = np.ascontiguousarray(src)
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().orc_resize_linear_u8(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dw, dh, dw)
+    return dst
+
+
+def gauss7(src):
+    src = np.ascontiguousarray(src)
+    dst = np.zeros_like(src)
+    lib().orc_gauss7(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dst.strides[0])
+    return dst
+
+
+def fast(img, thr):
+    img = np.ascontiguousarray(img)
+    cap = img.size // 4 + 16
+    out = np.zeros((cap, 3), np.int32)
+    n = lib().orc_fast(_p(img), img.shape[1], img.shape[0], img.strides[0], thr, _p(out), cap)
+    return out[:n]
+
+
+def octree(xys, minX, maxX, minY, maxY, N):
+    xys = np.ascontiguousarray(xys, np.int32)
+    sel = np.zeros(len(xys) + 16, np.int32)
+    n = lib().orc_octree(_p(xys), len(xys), minX, maxX, minY, maxY, N, _p(sel), len(sel))
+    return sel[:n]
+
+
+def sort_sized_nodes(size, ulx):
+    size = np.ascontiguousarray(size, np.int32)
+    ulx = np.ascontiguousarray(ulx, np.int32)
+    perm = np.zeros(len(size), np.int32)
+    lib().orc_sort_sized_nodes(_p(size), _p(ulx), len(size), _p(perm))
+    return perm
+
+
+def hamming(a, b):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return lib().orc_hamming(_p(a), _p(b))
+
+
+def knn2(q, t):
+    q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+    t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+    idx = np.zeros((len(q), 2), np.uint32)
+    dist = np.zeros((len(q), 2), np.uint16)
+    lib().orc_knn2(_p(q), len(q), _p(t), len(t), _p(idx), _p(dist))
+    return idx, dist
+
+
+def stereo_band_match(kl, dl, kr, dr, scale_factors, n_rows, min_d, max_d):
+    kl = np.ascontiguousarray(kl, KP)
+    kr = np.ascontiguousarray(kr, KP)
+    dl = np.ascontiguousarray(dl, np.uint8)
+    dr = np.ascontiguousarray(dr, np.uint8)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    bi = np.zeros(len(kl), np.int32)
+    bd = np.zeros(len(kl), np.int32)
+    lib().orc_stereo_band_match(_p(kl), _p(dl), len(kl), _p(kr), _p(dr), len(kr), _p(sf), n_rows,
+                                min_d, max_d, _p(bi), _p(bd))
+    return bi, bd

@@ -1,0 +1,125 @@
+"""GPU parity of the extractor against the CPU oracle, stage by stage, through the C ABI."""
+import numpy as np
+import pytest
+
+import orb_slam3_amd as orbx
+
+pytestmark = pytest.mark.gpu
+
+ANGLE_TOL_DEG = float(np.degrees(1e-4))  # angles must agree within 1e-4 rad
+
+
+def adversarial(kind, w, h):
+    rng = np.random.default_rng(7)
+    if kind == "zeros":
+        return np.zeros((h, w), np.uint8)
+    if kind == "noise":
+        return rng.integers(0, 256, (h, w), dtype=np.uint8)
+    if kind == "checker":
+        yy, xx = np.mgrid[0:h, 0:w]
+        return (((yy // 8 + xx // 8) & 1) * 255).astype(np.uint8)
+    if kind == "ramp":
+        return np.tile(np.linspace(0, 255, w).astype(np.uint8), (h, 1))
+    if kind == "dots":
+        img = np.full((h, w), 40, np.uint8)
+        img[19::36, 19::36] = 255
+        img[20::38, 18::36] = 250
+        return img
+    raise ValueError(kind)
+
+
+def compare_full(oracle, img, params, lap, check_stages=True):
+    nf, sf, nl, ini, mn = params
+    ref = oracle.Extractor(nf, sf, nl, ini, mn)
+    st, rmono, rk, rd = ref.extract(img, lap)
+    assert st == 0
+    ex = orbx.ORBextractor(nf, sf, nl, ini, mn)
+    mono, k, d = ex(img, None, lap)
+    if check_stages:
+        for l in range(nl):
+            w, h, s = ref.level_dims(l)
+            assert ex.level_dims(l)[:2] == (w, h)
+            got = ex.debug_padded(0, l)
+            assert np.array_equal(got, ref.padded(l)[:, :w + 38]), "pyramid level %d" % l
+            assert np.array_equal(ex.mvImagePyramid[l], ref.padded(l)[19:19 + h, 19:19 + w])
+            rc = ref.candidates(l)
+            gc = ex.debug_candidates(0, l)
+            assert np.array_equal(gc, rc), "candidates level %d (%d vs %d)" % (l, len(gc), len(rc))
+            rkeys, _ = ref.keys(l)
+            gs = ex.debug_selected(0, l)
+            assert len(gs) == len(rkeys), "selected count level %d" % l
+            assert np.array_equal(gs[:, 0] + 16, rkeys["x"].astype(np.int32))
+            assert np.array_equal(gs[:, 1] + 16, rkeys["y"].astype(np.int32))
+            assert np.array_equal(gs[:, 2], rkeys["response"].astype(np.int32))
+            rb = ref.blurred(l)
+            if rb is not None:
+                assert np.array_equal(ex.debug_blurred(0, l), rb), "blur level %d" % l
+    assert mono == rmono
+    assert len(k) == len(rk)
+    if len(rk) == 0:
+        assert d is None
+        return 0
+    for fld in ("x", "y", "size", "response", "octave", "class_id"):
+        assert np.array_equal(k[fld], rk[fld]), fld
+    dang = np.abs(k["angle"] - rk["angle"])
+    dang = np.minimum(dang, 360.0 - dang)
+    assert dang.max() <= ANGLE_TOL_DEG, dang.max()
+    bad = np.unpackbits(d ^ rd, axis=1).sum(axis=1) > 0
+    # descriptor bit differences are only tolerated on <= 0.1 % of the keypoints
+    assert bad.mean() <= 1e-3, "descriptor mismatches on %d of %d keypoints" % (bad.sum(), len(bad))
+    return int(bad.sum())
+
+
+def test_textured_752x480_mono(oracle):
+    img = orbx.textured_frame(0, 752, 480)
+    assert compare_full(oracle, img, (1000, 1.2, 8, 20, 7), (0, 1000)) == 0
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_textured_seeds(oracle, seed):
+    img = orbx.textured_frame(seed, 752, 480)
+    compare_full(oracle, img, (1200, 1.2, 8, 20, 7), (0, 0))
+
+
+@pytest.mark.parametrize("kind", ["zeros", "noise", "checker", "ramp", "dots"])
+def test_adversarial_320x240(oracle, kind):
+    img = adversarial(kind, 320, 240)
+    compare_full(oracle, img, (500, 1.2, 4, 20, 7), (100, 200))
+
+
+def test_noise_752x480_phase_b(oracle):
+    compare_full(oracle, adversarial("noise", 752, 480), (1000, 1.2, 8, 20, 7), (0, 0))
+
+
+@pytest.mark.parametrize("w,h,nf,lap", [(512, 512, 1500, (0, 511)), (1241, 376, 2000, (0, 0)),
+                                         (640, 480, 5000, (0, 1000))])
+def test_other_configs(oracle, w, h, nf, lap):
+    compare_full(oracle, orbx.textured_frame(11, w, h), (nf, 1.2, 8, 20, 7), lap)
+
+
+@pytest.mark.parametrize("nf,sf,nl", [(50, 1.2, 1), (1000, 1.5, 4), (300, 1.2, 8), (1000, 1.1, 8)])
+def test_param_sweep(oracle, nf, sf, nl):
+    compare_full(oracle, orbx.textured_frame(5, 480, 360), (nf, sf, nl, 20, 7), (100, 400))
+
+
+def test_batch_equals_single(oracle):
+    imgs = np.stack([orbx.textured_frame(s, 376, 240) for s in range(5)])
+    ex = orbx.ORBextractor(400, 1.2, 6, 20, 7, max_batch=8)
+    res = ex.extract_batch(imgs, (0, 0))
+    ref = oracle.Extractor(400, 1.2, 6, 20, 7)
+    for f in range(5):
+        st, rmono, rk, rd = ref.extract(imgs[f], (0, 0))
+        mono, k, d = res[f]
+        assert mono == rmono and len(k) == len(rk)
+        for fld in ("x", "y", "size", "response", "octave"):
+            assert np.array_equal(k[fld], rk[fld])
+        assert np.array_equal(d, rd)
+
+
+def test_errors():
+    ex = orbx.ORBextractor(100, 1.2, 8, 20, 7)
+    mono, k, d = ex(np.zeros((0, 0), np.uint8))
+    assert mono == -1 and len(k) == 0 and d is None
+    with pytest.raises(orbx.OrbxError) as e:
+        ex(np.zeros((100, 100), np.uint8))
+    assert e.value.status == -2
