@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Throughput bench of the ORB extractor hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+
+A step is one batched extraction (pyramid, FAST cells, quadtree, orientation,
+blur, descriptors) of `--batch` synthetic 752x480 frames that are already
+resident in HBM; outputs stay in HBM.  One process per GPU; for N > 1 launch
+through torch.distributed.run (RCCL is only used for the timing barrier: frames
+are independent, so the data path has no collective and scaling is weak).
+Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H = 752, 480
+PARAMS = (1000, 1.2, 8, 20, 7)   # nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST
+LAP = (0, 1000)                  # monocular call, core/src/Frame.cc:360
+HBM_PEAK_GBS = 8000.0
+
+
+def level_sizes(w, h, nlevels, scale_factor):
+    sizes, s = [], np.float32(1.0)
+    for l in range(nlevels):
+        inv = np.float32(1.0) / s
+        sizes.append((int(np.rint(np.float32(w) * inv)), int(np.rint(np.float32(h) * inv))))
+        s = np.float32(np.float64(s) * np.float64(np.float32(scale_factor)))
+    return sizes
+
+
+def algorithmic_bytes(w, h, nlevels, scale_factor, nkp):
+    """Per-frame algorithmic HBM bytes of each bandwidth-bound stage (unfused minimum):
+    pyramid = input + padded planes written + resize sources read; fast = padded planes
+    read; blur = level images read + written; whole frame adds 60 B per keypoint."""
+    sz = level_sizes(w, h, nlevels, scale_factor)
+    A = [a * b for a, b in sz]
+    P = [(a + 38) * (b + 38) for a, b in sz]
+    stage = {"pyramid": w * h + sum(P) + sum(A[:-1]), "fast": sum(P), "blur": 2 * sum(A)}
+    total = w * h + 2 * sum(P) + 2 * sum(A) + sum(A[:-1]) + nkp * 60
+    return stage, total
+
+
+def cpu_baseline(frames, seconds_budget=15.0):
+    """The CPU oracle (a restatement of the reference extractor; the reference itself needs
+    OpenCV and cannot be built here) on this host's cores, one extractor per thread,
+    independent frames - the reference's thread-per-camera model (core/src/Frame.cc:151-154)."""
+    from tests import oracle_lib as O
+    import subprocess
+    so = os.path.join(ROOT, "oracle", "liborb_oracle.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    ncores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    ncores = max(1, min(ncores, len(os.sched_getaffinity(0))))
+    # calibrate with one frame, then size the sample for ~seconds_budget of wall time
+    ex = O.Extractor(*PARAMS)
+    t0 = time.perf_counter()
+    ex.extract(frames[0], LAP)
+    one = time.perf_counter() - t0
+    per_thread = max(2, min(int(seconds_budget / max(one, 1e-4)), 400))
+    done = [0] * ncores
+
+    def work(tid):
+        e = O.Extractor(*PARAMS)
+        for i in range(per_thread):
+            e.extract(frames[(tid * per_thread + i) % len(frames)], LAP)
+            done[tid] += 1
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(ncores)]
+    t0 = time.perf_counter()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    dt = time.perf_counter() - t0
+    total = sum(done)
+    return {"value": total / dt, "unit": "frames/s", "cores": ncores, "kind": "port",
+            "sample": "%d synthetic 752x480 frames on %d threads (%.1f s), CPU oracle "
+                      "oracle/orb_oracle.cpp -O2, one extractor per thread" % (total, ncores, dt),
+            "single_thread_ms_per_frame": one * 1e3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=512, help="frames per step per GPU")
+    ap.add_argument("--distinct", type=int, default=32, help="distinct synthetic frames (tiled to the batch)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import orb_slam3_amd as orbx
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    B = args.batch
+    frames = np.stack([orbx.textured_frame(1000 * rank + i, W, H) for i in range(args.distinct)])
+    reps = (B + args.distinct - 1) // args.distinct
+    d_imgs = torch.from_numpy(np.tile(frames, (reps, 1, 1))[:B].copy()).to(dev)
+    torch.cuda.synchronize()
+
+    ex = orbx.ORBextractor(*PARAMS, device=local_rank, max_batch=B)
+
+    def step():
+        ex.extract_batch_device(d_imgs.data_ptr(), B, W, H, W, LAP)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        ex.sync()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ex.sync()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    barrier()
+
+    # per-stage kernel time from HIP events on the extractor's own stream
+    ex.set_profiling(True)
+    acc = {}
+    nprof = max(3, min(args.steps, 10))
+    for _ in range(nprof):
+        step()
+        ex.sync()
+        for k, v in ex.stage_times_ms().items():
+            acc[k] = acc.get(k, 0.0) + v / nprof
+    ex.set_profiling(False)
+
+    # keypoints per frame (for the algorithmic byte count and as a sanity figure)
+    step()
+    ex.sync()
+    nkp = float(np.mean([len(ex.download(f)[1]) for f in range(min(B, 8))]))
+
+    if rank == 0:
+        stage_bytes, frame_bytes = algorithmic_bytes(W, H, PARAMS[2], PARAMS[1], int(round(nkp)))
+        fps = world * B * args.steps / dt
+        # dominant bandwidth-bound kernel = slowest of the stages that have an HBM roofline
+        dom = max(stage_bytes, key=lambda k: acc[k])
+        achieved = stage_bytes[dom] * B / (acc[dom] * 1e-3) / 1e9
+        out = {
+            "metric": "ORB frames/s @752x480,1000kp,8lvl",
+            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": "EuRoC-shaped monocular 752x480, ORBextractor 1000 kp / 8 levels / "
+                                   "scale 1.2 / FAST 20,7, vLappingArea (0,1000); inputs and outputs "
+                                   "resident in HBM", "frames_per_step_per_gpu": B,
+                       "keypoints_per_frame": nkp, "parallelism": "frames sharded, no collective"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_frame": stage_bytes[dom]},
+            "stage_ms_per_step": acc,
+            "whole_frame_roofline_frac": fps / world * frame_bytes / (HBM_PEAK_GBS * 1e9),
+        }
+        if not args.no_cpu and world == 1:
+            out["cpu_baseline"] = cpu_baseline(frames)
+            out["gpu_over_cpu"] = fps / out["cpu_baseline"]["value"]
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

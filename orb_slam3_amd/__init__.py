@@ -10,5 +10,5 @@ ABI of include/orbx.h); this package only marshals arguments.
 from ._lib import KEYPOINT_DTYPE, OrbxError, lib  # noqa: F401
 from .extractor import ORBextractor  # noqa: F401
 from .matcher import (descriptor_distance, knn_match2, ratio_test, stereo_band_match,  # noqa: F401
-                      knn_match2_sharded)
+                      knn_match2_sharded, shard_bounds)
 from .synth import textured_frame  # noqa: F401

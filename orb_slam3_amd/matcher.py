@@ -57,62 +57,64 @@ def stereo_band_match(kps_l, desc_l, kps_r, desc_r, scale_factors, n_rows, min_d
     return bi, bd
 
 
-def knn_match2_sharded(query_t, train_shard_t, shard_offset, group=None):
+def shard_bounds(n_rows, world):
+    """Contiguous train-row ranges [b[r], b[r+1]) per rank, starts aligned to 8 rows.
+    Contiguous ranges keep global index order = (rank, local index) order, so merging
+    per-shard results in rank order reproduces the single-GPU tie-break."""
+    b = [(n_rows * r // world) // 8 * 8 for r in range(world)] + [n_rows]
+    return b
+
+
+def knn_match2_sharded(query_t, train_shard_t, shard_offset, group=None, _hooks=None):
     """Brute-force 2-NN against a train set sharded over the ranks of a
-    torch.distributed group.  query_t: (nq, 32) uint8 tensor replicated on every
-    rank; train_shard_t: this rank's contiguous slice of the train rows, whose
-    first row has global index shard_offset.  Every rank returns the global
-    (idx, dist) tensors.  One all-gather of the per-shard top-2 records is the
-    only exchange; on GPUs it runs over RCCL, and the merge is a HIP kernel.
-    On CPU tensors (gloo) the same exchange is followed by a numpy merge of the
-    records - that path exists to test the sharding logic without a GPU and
-    still needs the HIP library for the per-shard search."""
+    torch.distributed group (one process per GPU, RCCL over xGMI).
+
+    query_t: (nq, 32) uint8 CUDA tensor replicated on every rank; train_shard_t: this
+    rank's contiguous slice of the train rows, whose first row has global index
+    shard_offset.  Every rank returns the global (idx int32[nq,2], dist int16[nq,2])
+    tensors (bit patterns of uint32 / uint16).  The only exchange is one all-gather of
+    the per-shard top-2 records; the merge is a HIP kernel.
+
+    _hooks = (local_search, merge) replaces the two HIP calls; it exists so the
+    world_size-2 gloo test can drive this exchange on CPU tensors.  Without hooks CPU
+    tensors are rejected: there is no CPU implementation in this package."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     nq = query_t.shape[0]
-    on_gpu = query_t.is_cuda
-    if on_gpu:
+    if _hooks is None:
+        if not query_t.is_cuda or not train_shard_t.is_cuda:
+            raise RuntimeError("knn_match2_sharded needs CUDA tensors (no CPU fallback)")
         dev = query_t.device
-        idx = torch.empty((nq, 2), dtype=torch.int32, device=dev)
-        dst = torch.empty((nq, 2), dtype=torch.int16, device=dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
-        check(lib().orbx_knn2_device(C.c_void_p(query_t.data_ptr()), nq,
-                                     C.c_void_p(train_shard_t.data_ptr()), train_shard_t.shape[0],
-                                     int(shard_offset), C.c_void_p(idx.data_ptr()),
-                                     C.c_void_p(dst.data_ptr()), C.c_void_p(stream)), "orbx_knn2_device")
+
+        def local_search(q, t, off):
+            idx = torch.empty((nq, 2), dtype=torch.int32, device=dev)
+            dst = torch.empty((nq, 2), dtype=torch.int16, device=dev)
+            check(lib().orbx_knn2_device(C.c_void_p(q.data_ptr()), nq, C.c_void_p(t.data_ptr()),
+                                         t.shape[0], int(off), C.c_void_p(idx.data_ptr()),
+                                         C.c_void_p(dst.data_ptr()), C.c_void_p(stream)),
+                  "orbx_knn2_device")
+            return idx, dst
+
+        def merge(idx_all, dst_all):
+            out_i = torch.empty((nq, 2), dtype=torch.int32, device=dev)
+            out_d = torch.empty((nq, 2), dtype=torch.int16, device=dev)
+            check(lib().orbx_top2_merge_device(C.c_void_p(idx_all.data_ptr()),
+                                               C.c_void_p(dst_all.data_ptr()), idx_all.shape[0], nq,
+                                               C.c_void_p(out_i.data_ptr()), C.c_void_p(out_d.data_ptr()),
+                                               C.c_void_p(stream)), "orbx_top2_merge_device")
+            return out_i, out_d
     else:
-        i_np, d_np = knn_match2(query_t.numpy(), train_shard_t.numpy())
-        have = i_np != 0xFFFFFFFF
-        i_np = np.where(have, i_np + np.uint32(shard_offset), i_np)
-        idx = torch.from_numpy(i_np.view(np.int32))
-        dst = torch.from_numpy(d_np.view(np.int16))
+        local_search, merge = _hooks
+
+    idx, dst = local_search(query_t.contiguous(), train_shard_t.contiguous(), shard_offset)
     if world == 1:
         return idx, dst
-    idx_all = torch.empty((world, nq, 2), dtype=idx.dtype, device=idx.device)
-    dst_all = torch.empty((world, nq, 2), dtype=dst.dtype, device=dst.device)
-    dist.all_gather_into_tensor(idx_all, idx, group=group)
-    dist.all_gather_into_tensor(dst_all, dst, group=group)
-    if on_gpu:
-        out_i = torch.empty_like(idx)
-        out_d = torch.empty_like(dst)
-        stream = torch.cuda.current_stream(idx.device).cuda_stream
-        check(lib().orbx_top2_merge_device(C.c_void_p(idx_all.data_ptr()), C.c_void_p(dst_all.data_ptr()),
-                                           world, nq, C.c_void_p(out_i.data_ptr()),
-                                           C.c_void_p(out_d.data_ptr()), C.c_void_p(stream)),
-              "orbx_top2_merge_device")
-        return out_i, out_d
-    out_i, out_d = merge_top2_host(idx_all.numpy().view(np.uint32), dst_all.numpy().view(np.uint16))
-    return torch.from_numpy(out_i.view(np.int32)), torch.from_numpy(out_d.view(np.int16))
-
-
-def merge_top2_host(idx_parts, dist_parts):
-    """Host restatement of the top-2 merge: parts [P, nq, 2] -> global [nq, 2]
-    ordered by (distance, index)."""
-    P, nq, _ = idx_parts.shape
-    key = (dist_parts.astype(np.uint64) << np.uint64(32)) | idx_parts.astype(np.uint64)
-    key = np.transpose(key, (1, 0, 2)).reshape(nq, 2 * P)
-    key.sort(axis=1)
-    best = key[:, :2]
-    return (best & np.uint64(0xFFFFFFFF)).astype(np.uint32), (best >> np.uint64(32)).astype(np.uint16)
+    idx_all = torch.empty((world * nq, 2), dtype=idx.dtype, device=idx.device)
+    # 16-bit integers are not a collective dtype (neither RCCL nor gloo): ship the bytes
+    dst_all = torch.empty((world * nq, 4), dtype=torch.uint8, device=dst.device)
+    dist.all_gather_into_tensor(idx_all, idx.contiguous(), group=group)
+    dist.all_gather_into_tensor(dst_all, dst.contiguous().view(torch.uint8), group=group)
+    return merge(idx_all.view(world, nq, 2), dst_all.view(torch.int16).view(world, nq, 2))

@@ -1,0 +1,78 @@
+"""world_size-2 (and 3) gloo run of the sharded 2-NN exchange on CPU tensors.  The per-shard
+search and the merge are injected from the oracle / numpy so that the product's sharding,
+offset and all-gather logic runs without a GPU; on a GPU box the same function runs the HIP
+kernels (tests/test_gpu_match.py covers those)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def merge_top2_numpy(idx_parts, dist_parts):
+    P, nq, _ = idx_parts.shape
+    key = (dist_parts.astype(np.uint64) << np.uint64(32)) | idx_parts.astype(np.uint64)
+    key = np.transpose(key, (1, 0, 2)).reshape(nq, 2 * P)
+    key.sort(axis=1)
+    best = key[:, :2]
+    return (best & np.uint64(0xFFFFFFFF)).astype(np.uint32), (best >> np.uint64(32)).astype(np.uint16)
+
+
+def _worker(rank, world, port, q, t, out):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import orb_slam3_amd as orbx
+    from tests import oracle_lib as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def local_search(qt, tt, off):
+        i, d = O.knn2(qt.numpy(), tt.numpy())
+        i = np.where(i != 0xFFFFFFFF, i + np.uint32(off), i)
+        return torch.from_numpy(i.view(np.int32).copy()), torch.from_numpy(d.view(np.int16).copy())
+
+    def merge(ia, da):
+        i, d = merge_top2_numpy(ia.numpy().view(np.uint32), da.numpy().view(np.uint16))
+        return torch.from_numpy(i.view(np.int32).copy()), torch.from_numpy(d.view(np.int16).copy())
+
+    b = orbx.shard_bounds(len(t), world)
+    shard = torch.from_numpy(t[b[rank]:b[rank + 1]].copy())
+    i, d = orbx.knn_match2_sharded(torch.from_numpy(q), shard, b[rank], _hooks=(local_search, merge))
+    out[rank] = (i.numpy().view(np.uint32).copy(), d.numpy().view(np.uint16).copy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_knn_equals_unsharded(oracle, world):
+    import torch.multiprocessing as mp
+    rng = np.random.default_rng(world)
+    t = rng.integers(0, 256, (2001, 32), dtype=np.uint8)
+    t = np.repeat(t[:400], 6, axis=0)[:2001]          # duplicates across shard boundaries
+    q = t[rng.integers(0, len(t), 150)].copy()
+    q[::3] ^= rng.integers(0, 256, (50, 32), dtype=np.uint8) & 0x11
+    ridx, rdist = oracle.knn2(q, t)
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, t, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert np.array_equal(out[r][0], ridx) and np.array_equal(out[r][1], rdist)

@@ -1,0 +1,70 @@
+"""Committed golden vectors (tests/golden/*.npz, made by tests/golden/make_golden.py from
+the CPU oracle).  CPU: the oracle still reproduces them.  GPU: the HIP path reproduces them
+without the oracle being present."""
+import glob
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+import orb_slam3_amd as orbx
+
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = sorted(p for p in glob.glob(os.path.join(HERE, "*.npz")) if "knn2" not in p)
+
+
+def load(path):
+    g = np.load(path)
+    prm = g["params"]
+    params = (int(prm[0]), float(prm[1]), int(prm[2]), int(prm[3]), int(prm[4]))
+    img = orbx.textured_frame(int(g["seed"]), int(g["w"]), int(g["h"]))
+    assert zlib.crc32(img.tobytes()) == int(g["image_crc32"])
+    return g, params, img, tuple(int(v) for v in g["lap"])
+
+
+def test_fixtures_exist():
+    assert len(CASES) == 4
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p) for p in CASES])
+def test_oracle_reproduces_golden(oracle, path):
+    g, params, img, lap = load(path)
+    e = oracle.Extractor(*params)
+    st, mono, k, d = e.extract(img, lap)
+    assert st == 0 and mono == int(g["mono"])
+    assert np.array_equal(k, g["keypoints"]) and np.array_equal(d, g["descriptors"])
+    crc = [zlib.crc32(e.padded(l)[:, :e.level_dims(l)[0] + 38].tobytes()) for l in range(params[2])]
+    assert crc == g["pyramid_crc32"].tolist()
+
+
+def test_oracle_knn_golden(oracle):
+    g = np.load(os.path.join(HERE, "knn2_200x3000.npz"))
+    idx, dist = oracle.knn2(g["q"], g["t"])
+    assert np.array_equal(idx, g["idx"]) and np.array_equal(dist, g["dist"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p) for p in CASES])
+def test_hip_reproduces_golden(path):
+    g, params, img, lap = load(path)
+    ex = orbx.ORBextractor(*params)
+    mono, k, d = ex(img, None, lap)
+    gk = g["keypoints"]
+    assert mono == int(g["mono"]) and len(k) == len(gk)
+    for fld in ("x", "y", "size", "response", "octave", "class_id"):
+        assert np.array_equal(k[fld], gk[fld]), fld
+    dang = np.abs(k["angle"] - gk["angle"])
+    assert np.minimum(dang, 360 - dang).max() <= np.degrees(1e-4)
+    bad = (np.unpackbits(d ^ g["descriptors"], axis=1).sum(axis=1) > 0)
+    assert bad.mean() <= 1e-3
+    for l in range(params[2]):
+        w = ex.level_dims(l)[0]
+        assert zlib.crc32(np.ascontiguousarray(ex.debug_padded(0, l)[:, :w + 38]).tobytes()) == int(g["pyramid_crc32"][l])
+
+
+@pytest.mark.gpu
+def test_hip_knn_golden():
+    g = np.load(os.path.join(HERE, "knn2_200x3000.npz"))
+    idx, dist = orbx.knn_match2(g["q"], g["t"])
+    assert np.array_equal(idx, g["idx"]) and np.array_equal(dist, g["dist"])

@@ -1,0 +1,137 @@
+"""GPU parity of the Hamming matchers against the CPU oracle (bit-exact, ties included)."""
+import numpy as np
+import pytest
+
+import orb_slam3_amd as orbx
+
+pytestmark = pytest.mark.gpu
+
+
+def rand_desc(rng, n):
+    return rng.integers(0, 256, (n, 32), dtype=np.uint8)
+
+
+def planted(rng, nq, nt, frac=0.3):
+    """Uniform random descriptors (distances ~128, many exact ties) with a fraction of the
+    queries planted as a train row with 0-40 flipped bits."""
+    t = rand_desc(rng, nt)
+    q = rand_desc(rng, nq)
+    for i in range(nq):
+        if rng.random() < frac and nt:
+            row = t[rng.integers(0, nt)].copy()
+            bits = np.unpackbits(row)
+            flips = rng.choice(256, rng.integers(0, 41), replace=False)
+            bits[flips] ^= 1
+            q[i] = np.packbits(bits)
+    return q, t
+
+
+@pytest.mark.parametrize("nq,nt", [(1, 1), (1, 2), (3, 0), (64, 64), (513, 1000), (1500, 1500),
+                                   (700, 20000), (5, 300000)])
+def test_knn2_matches_oracle(oracle, nq, nt):
+    rng = np.random.default_rng(nq * 131 + nt)
+    q, t = planted(rng, nq, nt)
+    idx, dist = orbx.knn_match2(q, t)
+    ridx, rdist = oracle.knn2(q, t)
+    assert np.array_equal(dist, rdist)
+    assert np.array_equal(idx, ridx)
+
+
+def test_knn2_duplicate_train_rows_tie_break(oracle):
+    rng = np.random.default_rng(3)
+    t = np.repeat(rand_desc(rng, 50), 40, axis=0)  # every row 40 times -> massive ties
+    rng.shuffle(t, axis=0)
+    q = t[rng.integers(0, len(t), 300)]
+    idx, dist = orbx.knn_match2(q, t)
+    ridx, rdist = oracle.knn2(q, t)
+    assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
+    assert (dist[:, 0] == 0).all() and (idx[:, 0] < idx[:, 1]).all()
+
+
+def test_knn2_device_sharded_merge(oracle):
+    """Shard the train set 1, 2, 4 and 8 ways in one process; merging the per-shard
+    results must reproduce the unsharded answer exactly."""
+    import ctypes as C
+    import torch
+    from orb_slam3_amd._lib import lib, check
+    rng = np.random.default_rng(11)
+    q, t = planted(rng, 777, 40000)
+    ridx, rdist = oracle.knn2(q, t)
+    dq = torch.from_numpy(q).cuda()
+    dt = torch.from_numpy(t).cuda()
+    for shards in (1, 2, 4, 8):
+        bounds = np.linspace(0, len(t), shards + 1).astype(int)
+        bounds = (bounds // 8) * 8
+        bounds[-1] = len(t)
+        pidx = torch.empty((shards, len(q), 2), dtype=torch.int32, device="cuda")
+        pdst = torch.empty((shards, len(q), 2), dtype=torch.int16, device="cuda")
+        for s in range(shards):
+            sl = dt[bounds[s]:bounds[s + 1]]
+            check(lib().orbx_knn2_device(C.c_void_p(dq.data_ptr()), len(q), C.c_void_p(sl.data_ptr()),
+                                         sl.shape[0], int(bounds[s]), C.c_void_p(pidx[s].data_ptr()),
+                                         C.c_void_p(pdst[s].data_ptr()), None))
+        oi = torch.empty((len(q), 2), dtype=torch.int32, device="cuda")
+        od = torch.empty((len(q), 2), dtype=torch.int16, device="cuda")
+        check(lib().orbx_top2_merge_device(C.c_void_p(pidx.data_ptr()), C.c_void_p(pdst.data_ptr()), shards,
+                                           len(q), C.c_void_p(oi.data_ptr()), C.c_void_p(od.data_ptr()), None))
+        torch.cuda.synchronize()
+        assert np.array_equal(oi.cpu().numpy().view(np.uint32), ridx), shards
+        assert np.array_equal(od.cpu().numpy().view(np.uint16), rdist), shards
+
+
+def test_hamming_is_popcount(oracle):
+    rng = np.random.default_rng(5)
+    a, b = rand_desc(rng, 200), rand_desc(rng, 200)
+    for i in range(200):
+        want = int(np.unpackbits(a[i] ^ b[i]).sum())
+        assert orbx.descriptor_distance(a[i], b[i]) == want == oracle.hamming(a[i], b[i])
+
+
+def test_stereo_pair_extract_and_band_match(oracle):
+    """Config 2 shape: a 752x480 stereo pair (right = left shifted), 1200 kp per camera,
+    extraction followed by the row-band descriptor search."""
+    left = orbx.textured_frame(21, 752 + 40, 480)
+    right = np.ascontiguousarray(left[:, 25:25 + 752])
+    left = np.ascontiguousarray(left[:, :752])
+    exl = orbx.ORBextractor(1200, 1.2, 8, 20, 7)
+    exr = orbx.ORBextractor(1200, 1.2, 8, 20, 7)
+    _, kl, dl = exl(left, None, (0, 0))
+    _, kr, dr = exr(right, None, (0, 0))
+    sf = exl.GetScaleFactors()
+    bi, bd = orbx.stereo_band_match(kl, dl, kr, dr, sf, 480, 0.0, 435.0)
+    ri, rd = oracle.stereo_band_match(kl, dl, kr, dr, sf, 480, 0.0, 435.0)
+    assert np.array_equal(bi, ri) and np.array_equal(bd, rd)
+    assert (bd < 75).sum() > 100  # plenty of accepted matches on a shifted copy
+
+
+def test_stereo_band_random(oracle):
+    rng = np.random.default_rng(9)
+    n = 900
+    def kps():
+        k = np.zeros(n, orbx.KEYPOINT_DTYPE)
+        k["x"] = rng.uniform(20, 700, n).astype(np.float32)
+        k["y"] = rng.uniform(20, 460, n).astype(np.float32)
+        k["octave"] = rng.integers(0, 8, n)
+        return k
+    kl, kr = kps(), kps()
+    base = rand_desc(rng, 30)
+    dl = base[rng.integers(0, 30, n)]
+    dr = base[rng.integers(0, 30, n)]  # few distinct descriptors -> distance ties
+    sf = (1.2 ** np.arange(8)).astype(np.float32)
+    bi, bd = orbx.stereo_band_match(kl, dl, kr, dr, sf, 480, 0.0, 300.0)
+    ri, rd = oracle.stereo_band_match(kl, dl, kr, dr, sf, 480, 0.0, 300.0)
+    assert np.array_equal(bi, ri) and np.array_equal(bd, rd)
+
+
+def test_fisheye_config_knn_on_lapping_subsets(oracle):
+    """Config 3 shape: 512x512 pair, 1500 kp, lapping area -> 2-NN between the lapping subsets
+    (rows [mono:], core/src/Frame.cc:1159-1177) + ratio test."""
+    a = orbx.textured_frame(31, 512, 512)
+    b = np.roll(a, 9, axis=1)
+    ex = orbx.ORBextractor(1500, 1.2, 8, 20, 7)
+    ml, kl, dl = ex(a, None, (100, 511))
+    mr, kr, dr = ex(b, None, (0, 400))
+    idx, dist = orbx.knn_match2(dl[ml:], dr[mr:])
+    ridx, rdist = oracle.knn2(dl[ml:], dr[mr:])
+    assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
+    assert orbx.ratio_test(idx, dist).sum() > 50

@@ -1,0 +1,78 @@
+"""Host-side checks that need no GPU: the C-ABI library loads and exports every symbol
+declared in include/orbx.h, the std::sort restatement used by the quadtree kernel matches
+libstdc++, status strings, synthetic frames, shard arithmetic."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    hdr = open(os.path.join(ROOT, "include", "orbx.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(orbx_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    from orb_slam3_amd import _lib
+    L = _lib.lib()
+    names = declared_functions()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(L, n), "liborbx_hip.so does not export %s" % n
+    assert set(_lib.SIGNATURES) == set(names), set(_lib.SIGNATURES) ^ set(names)
+
+
+def test_status_strings_and_host_helpers():
+    import orb_slam3_amd as orbx
+    from orb_slam3_amd import _lib
+    L = _lib.lib()
+    for st in range(-8, 1):
+        assert L.orbx_strerror(st) not in (None, b"unknown status")
+    assert L.orbx_strerror(-99) == b"unknown status"
+    a = np.arange(32, dtype=np.uint8)
+    assert orbx.descriptor_distance(a, a) == 0
+    assert orbx.descriptor_distance(np.zeros(32, np.uint8), np.full(32, 0x0F, np.uint8)) == 128
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    import orb_slam3_amd as orbx
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(orbx.OrbxError) as e:
+        orbx.ORBextractor(1000, 1.2, 8, 20, 7)
+    assert e.value.status == -5
+    with pytest.raises(orbx.OrbxError):
+        orbx.knn_match2(np.zeros((4, 32), np.uint8), np.zeros((4, 32), np.uint8))
+
+
+def test_synth_frames_are_deterministic():
+    import orb_slam3_amd as orbx
+    a = orbx.textured_frame(5, 320, 240)
+    assert np.array_equal(a, orbx.textured_frame(5, 320, 240))
+    assert not np.array_equal(a, orbx.textured_frame(6, 320, 240))
+    assert 40 < a.std() < 90
+
+
+def test_std_sort_restatement_matches_libstdcxx(tmp_path):
+    exe = str(tmp_path / "test_stdsort")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe,
+                           os.path.join(ROOT, "tests", "cpp", "test_stdsort.cpp")])
+    out = subprocess.check_output([exe]).decode()
+    assert out.startswith("OK")
+
+
+def test_shard_bounds_cover_everything_once():
+    import orb_slam3_amd as orbx
+    for n in (0, 1, 7, 1000, 10_000_001):
+        for world in (1, 2, 4, 8):
+            b = orbx.shard_bounds(n, world)
+            assert b[0] == 0 and b[-1] == n and len(b) == world + 1
+            assert all(b[i] <= b[i + 1] for i in range(world))
+            assert all(x % 8 == 0 for x in b[:-1])
