@@ -214,7 +214,7 @@ int orbx_extractor::ensurePlan(int W, int H) {
 
   size_t pyrOff = 0, blurOff = 0;
   uint32_t candOff = 0, flatOff = 0;
-  int cellFirst = 0, tileFirst = 0, selOff = 0, nodesCap = 0, cellsMax = 0;
+  int cellFirst = 0, tileFirst = 0, selOff = 0, nodesCap = 0, cellsMax = 0, cwMax = 0, chMax = 0;
   for (int l = 0; l < nl; ++l) {
     LevelDesc& L = hp.lv[l];
     L.w = cv_round((float)W * invScale[l]);  // extractor.cc:1105-1107
@@ -239,6 +239,8 @@ int orbx_extractor::ensurePlan(int W, int H) {
     L.cell_first = cellFirst;
     cellFirst += L.ncx * L.ncy;
     cellsMax = std::max(cellsMax, L.ncx * L.ncy);
+    cwMax = std::max(cwMax, L.wCell);
+    chMax = std::max(chMax, L.hCell);
     L.cand_cap_cell = ((L.wCell + 1) / 2) * ((L.hCell + 1) / 2);
     L.cand_off = candOff;
     const uint64_t levelCand = (uint64_t)L.ncx * L.ncy * L.cand_cap_cell;
@@ -269,8 +271,8 @@ int orbx_extractor::ensurePlan(int W, int H) {
     L.blur_plane = (size_t)L.bstride * L.h;
     L.blur_off = blurOff;
     blurOff += L.blur_plane * B;
-    L.tiles_x = (L.w + 63) / 64;
-    L.tiles_y = (L.h + 31) / 32;
+    L.tiles_x = (L.w + 255) / 256;   // k_blur: a block covers 256 columns x 256 rows
+    L.tiles_y = (L.h + 255) / 256;
     L.tile_first = tileFirst;
     tileFirst += L.tiles_x * L.tiles_y;
   }
@@ -280,6 +282,11 @@ int orbx_extractor::ensurePlan(int W, int H) {
   hp.flat_frame = flatOff;
   hp.sel_frame = selOff;
   hp.kp_cap = selOff;
+  hp.fast_ts = cwMax <= 40 ? 48 : (cwMax <= 56 ? 64 : 80);
+  hp.fast_tile_rows = chMax + 7;
+  hp.fast_mm_rows = chMax + 2;
+  hp.fast_qcap = (cwMax * chMax + 7) / 8 * 8;
+  hp.fast_words = (cwMax * chMax + 31) / 32;
   hp.oct_nodes_cap = nodesCap;
   hp.oct_cells_max = cellsMax;
   maxKeypoints = selOff;

@@ -123,28 +123,39 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const uint8_t* __restrict__ 
 // on the cell's ROI, so suppression only sees neighbours inside the cell's own
 // detection domain; domains tile [19, w-19) x [19, h-19) without overlap.
 // ---------------------------------------------------------------------------
-#define FAST_TS 80  // LDS row stride of the image tile (>= 70 + 6)
-#define FAST_MS 76  // LDS row stride of the m map (>= 70 + 2)
-
+// Implementation: one wave per cell.
+//   1. the cell's pixels plus a 3-pixel ring halo go to LDS (aligned dword
+//      loads, re-based with v_alignbyte so that cell column 0 sits at LDS
+//      column 4 and a lane's 4-pixel group is dword-aligned);
+//   2. quick rejection for every pixel, 8 pixels (4 columns x 2 rows) per lane
+//      and two pixels per instruction (packed 16-bit min/max): a 9-arc holds
+//      one pixel of each of the 8 opposite ring pairs, so a corner needs
+//      max_k min(I_k, I_k+8) < v - t  or  min_k max(I_k, I_k+8) > v + t;
+//      survivors (a few percent of the pixels) are queued in LDS;
+//   3. the exact m for queued pixels only, one pixel per lane;
+//   4. suppression + threshold choice + ordered output through bit masks in
+//      raster order.
+// TS = LDS row stride in bytes of the tile and of the m map (cell width <= TS - 8).
+template <int TS>
 __device__ __forceinline__ int fast_m(const uint8_t* c) {
   const int v = c[0];
   int d[16];
-  d[0] = v - c[3 * FAST_TS + 0];
-  d[1] = v - c[3 * FAST_TS + 1];
-  d[2] = v - c[2 * FAST_TS + 2];
-  d[3] = v - c[1 * FAST_TS + 3];
+  d[0] = v - c[3 * TS + 0];
+  d[1] = v - c[3 * TS + 1];
+  d[2] = v - c[2 * TS + 2];
+  d[3] = v - c[1 * TS + 3];
   d[4] = v - c[3];
-  d[5] = v - c[-1 * FAST_TS + 3];
-  d[6] = v - c[-2 * FAST_TS + 2];
-  d[7] = v - c[-3 * FAST_TS + 1];
-  d[8] = v - c[-3 * FAST_TS + 0];
-  d[9] = v - c[-3 * FAST_TS - 1];
-  d[10] = v - c[-2 * FAST_TS - 2];
-  d[11] = v - c[-1 * FAST_TS - 3];
+  d[5] = v - c[-1 * TS + 3];
+  d[6] = v - c[-2 * TS + 2];
+  d[7] = v - c[-3 * TS + 1];
+  d[8] = v - c[-3 * TS + 0];
+  d[9] = v - c[-3 * TS - 1];
+  d[10] = v - c[-2 * TS - 2];
+  d[11] = v - c[-1 * TS - 3];
   d[12] = v - c[-3];
-  d[13] = v - c[1 * FAST_TS - 3];
-  d[14] = v - c[2 * FAST_TS - 2];
-  d[15] = v - c[3 * FAST_TS - 1];
+  d[13] = v - c[1 * TS - 3];
+  d[14] = v - c[2 * TS - 2];
+  d[15] = v - c[3 * TS - 1];
   int lo2[16], hi2[16], lo4[16], hi4[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
@@ -168,16 +179,71 @@ __device__ __forceinline__ int fast_m(const uint8_t* c) {
   return max(max(best_dark, -best_bright), 0);
 }
 
-__global__ __launch_bounds__(256) void k_fast_cells(const Plan* __restrict__ plan,
-                                                    const uint8_t* __restrict__ pyr,
-                                                    uint32_t* __restrict__ cand,
-                                                    int* __restrict__ cellCount) {
-  __shared__ uint8_t tile[(ORBX_CELL_MAX + 6) * FAST_TS];
-  __shared__ uint8_t mm[(ORBX_CELL_MAX + 2) * FAST_MS];
-  __shared__ uint8_t selv[ORBX_CELL_MAX * ORBX_CELL_MAX];
-  __shared__ int chunkCnt[96];
+typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+typedef short ss2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us2_t, a), __builtin_bit_cast(us2_t, b)));
+}
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2_t, a), __builtin_bit_cast(us2_t, b)));
+}
+__device__ __forceinline__ uint32_t pk_add_u16(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2_t, a) + __builtin_bit_cast(us2_t, b));
+}
+__device__ __forceinline__ uint32_t pk_sub_i16(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_bit_cast(ss2_t, a) - __builtin_bit_cast(ss2_t, b));
+}
+__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(ss2_t, a), __builtin_bit_cast(ss2_t, b)));
+}
 
-  const int tid = threadIdx.x;
+// Bytes B0 and B0+2 of a 12-byte window row (three dwords) as two 16-bit lanes.
+template <int B0>
+__device__ __forceinline__ uint32_t pick2(const uint32_t (&row)[3]) {
+  static_assert(B0 >= 0 && B0 + 2 < 12, "byte index");
+  if (B0 + 2 <= 7) {
+    return __builtin_amdgcn_perm(row[1], row[0], 0x0c000c00u | (uint32_t)B0 | ((uint32_t)(B0 + 2) << 16));
+  } else {
+    return __builtin_amdgcn_perm(row[2], row[1], 0x0c000c00u | (uint32_t)(B0 - 4) | ((uint32_t)(B0 - 2) << 16));
+  }
+}
+
+// Quick corner test for the two pixels at window bytes C and C+2 of window
+// row WR (R = 8 window rows x 3 dwords).  Returns a packed pair of signed
+// 16-bit values, positive where the pixel may be a corner at threshold t.
+template <int WR, int C>
+__device__ __forceinline__ uint32_t quick_pair(const uint32_t (&R)[8][3], uint32_t tt) {
+  const uint32_t v = pick2<C>(R[WR]);
+  // opposite ring pairs (dx,dy) / (-dx,-dy)
+  const uint32_t a0 = pick2<C + 0>(R[WR + 3]), b0 = pick2<C + 0>(R[WR - 3]);
+  const uint32_t a1 = pick2<C + 1>(R[WR + 3]), b1 = pick2<C - 1>(R[WR - 3]);
+  const uint32_t a2 = pick2<C + 2>(R[WR + 2]), b2 = pick2<C - 2>(R[WR - 2]);
+  const uint32_t a3 = pick2<C + 3>(R[WR + 1]), b3 = pick2<C - 3>(R[WR - 1]);
+  const uint32_t a4 = pick2<C + 3>(R[WR]),     b4 = pick2<C - 3>(R[WR]);
+  const uint32_t a5 = pick2<C + 3>(R[WR - 1]), b5 = pick2<C - 3>(R[WR + 1]);
+  const uint32_t a6 = pick2<C + 2>(R[WR - 2]), b6 = pick2<C - 2>(R[WR + 2]);
+  const uint32_t a7 = pick2<C + 1>(R[WR - 3]), b7 = pick2<C - 1>(R[WR + 3]);
+  uint32_t lo = pk_min_u16(a0, b0), hi = pk_max_u16(a0, b0);
+  lo = pk_max_u16(lo, pk_min_u16(a1, b1)); hi = pk_min_u16(hi, pk_max_u16(a1, b1));
+  lo = pk_max_u16(lo, pk_min_u16(a2, b2)); hi = pk_min_u16(hi, pk_max_u16(a2, b2));
+  lo = pk_max_u16(lo, pk_min_u16(a3, b3)); hi = pk_min_u16(hi, pk_max_u16(a3, b3));
+  lo = pk_max_u16(lo, pk_min_u16(a4, b4)); hi = pk_min_u16(hi, pk_max_u16(a4, b4));
+  lo = pk_max_u16(lo, pk_min_u16(a5, b5)); hi = pk_min_u16(hi, pk_max_u16(a5, b5));
+  lo = pk_max_u16(lo, pk_min_u16(a6, b6)); hi = pk_min_u16(hi, pk_max_u16(a6, b6));
+  lo = pk_max_u16(lo, pk_min_u16(a7, b7)); hi = pk_min_u16(hi, pk_max_u16(a7, b7));
+  // dark arc possible: lo + t < v ; bright arc possible: hi > v + t
+  const uint32_t s1 = pk_sub_i16(v, pk_add_u16(lo, tt));
+  const uint32_t s2 = pk_sub_i16(hi, pk_add_u16(v, tt));
+  return pk_max_i16(s1, s2);
+}
+
+template <int TS>
+__global__ __launch_bounds__(64) void k_fast_cells(const Plan* __restrict__ plan,
+                                                   const uint8_t* __restrict__ pyr,
+                                                   uint32_t* __restrict__ cand,
+                                                   int* __restrict__ cellCount) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  const int lane = threadIdx.x;
   const int f = blockIdx.y;
   const int cellg = blockIdx.x;
   int l = 0;
@@ -188,78 +254,139 @@ __global__ __launch_bounds__(256) void k_fast_cells(const Plan* __restrict__ pla
   const int X0 = ORBX_EDGE + cj * L.wCell, Y0 = ORBX_EDGE + ci * L.hCell;
   const int cw = min(L.wCell, L.w - ORBX_EDGE - X0);
   const int ch = min(L.hCell, L.h - ORBX_EDGE - Y0);
-  const int tw = cw + 6, th = ch + 6;
-
-  // image tile with a 3-pixel ring halo; padded coords of its origin
-  const uint8_t* src = pyr + L.pyr_off + (size_t)f * L.pyr_plane +
-                       (size_t)(Y0 - 3 + ORBX_EDGE) * L.pstride + (X0 - 3 + ORBX_EDGE);
-  for (int r = tid >> 5; r < th; r += 8) {
-    const uint8_t* srow = src + (size_t)r * L.pstride;
-    for (int c = tid & 31; c < tw; c += 32) tile[r * FAST_TS + c] = srow[c];
-  }
-  for (int i = tid; i < (ch + 2) * FAST_MS; i += 256) mm[i] = 0;
-  __syncthreads();
-
   const int np = cw * ch;
-  const float rcw = 1.0f / (float)cw;
-  for (int p = tid; p < np; p += 256) {
-    const int y = (int)(((float)p + 0.5f) * rcw);
-    const int x = p - y * cw;
-    mm[(y + 1) * FAST_MS + x + 1] = (uint8_t)fast_m(&tile[(y + 3) * FAST_TS + x + 3]);
-  }
-  __syncthreads();
+  const int nwords = (np + 31) >> 5;
 
-  const int ini = plan->ini_th, mn = plan->min_th;
-  int anyIni = 0;
-  for (int p = tid; p < np; p += 256) {
-    const int y = (int)(((float)p + 0.5f) * rcw);
-    const int x = p - y * cw;
-    const uint8_t* q = &mm[(y + 1) * FAST_MS + x + 1];
-    const int m = q[0];
-    const bool isMax = m > 0 && m > q[-1] && m > q[1] && m > q[-FAST_MS - 1] && m > q[-FAST_MS] &&
-                       m > q[-FAST_MS + 1] && m > q[FAST_MS - 1] && m > q[FAST_MS] &&
-                       m > q[FAST_MS + 1];
-    selv[p] = isMax ? (uint8_t)m : (uint8_t)0;
-    anyIni |= (isMax && m > ini);
-  }
-  const int thr = __syncthreads_or(anyIni) ? ini : mn;
+  uint8_t* tile = smem;                                   // fast_tile_rows x TS
+  uint8_t* mm = tile + plan->fast_tile_rows * TS;         // fast_mm_rows x TS
+  uint16_t* queue = (uint16_t*)(mm + plan->fast_mm_rows * TS);
+  uint32_t* bitsIni = (uint32_t*)(queue + plan->fast_qcap);
+  uint32_t* bitsMin = bitsIni + plan->fast_words;
 
-  // ordered compaction: chunk = 64 consecutive pixels handled by one wave
-  const int wave = tid >> 6, lane = tid & 63;
-  const int nchunks = (np + 63) >> 6;
-  for (int cidx = wave; cidx < nchunks; cidx += 4) {
-    const int p = cidx * 64 + lane;
-    const bool keep = p < np && selv[p] > thr;
-    const unsigned long long mask = __ballot(keep);
-    if (lane == 0) chunkCnt[cidx] = __popcll(mask);
-  }
-  __syncthreads();
-  if (wave == 0) {
-    int running = 0;
-    for (int base = 0; base < nchunks; base += 64) {
-      const int i = base + lane;
-      const int v = i < nchunks ? chunkCnt[i] : 0;
-      const int inc = wave_incl_scan(v);
-      if (i < nchunks) chunkCnt[i] = running + inc - v;
-      running += __shfl(inc, 63, 64);
+  // ---- 1. tile: LDS (row r, col c) = level pixel (X0 - 4 + c, Y0 - 3 + r) ----
+  {
+    const int shift = (X0 + 15) & 3;  // planes and rows are 64-byte aligned
+    const uint8_t* g0 = pyr + L.pyr_off + (size_t)f * L.pyr_plane +
+                        (size_t)(Y0 - 3 + ORBX_EDGE) * L.pstride + (X0 - 4 + ORBX_EDGE - shift);
+    const int nd = (cw + 10) >> 2;
+    const int total = (ch + 6) * nd;
+    const float rnd = 1.0f / (float)nd;
+    for (int i = lane; i < total; i += 64) {
+      const int r = (int)(((float)i + 0.5f) * rnd);
+      const int n = i - r * nd;
+      const uint32_t* gp = (const uint32_t*)(g0 + (size_t)r * L.pstride) + n;
+      const uint32_t lo = gp[0], hi = gp[1];
+      *(uint32_t*)(tile + r * TS + 4 * n) = __builtin_amdgcn_alignbyte(hi, lo, shift);
     }
-    if (lane == 0) cellCount[(size_t)f * plan->cells_per_frame + cellg] = running;
+    const int mmq = ((ch + 2) * TS + 15) >> 4;
+    for (int i = lane; i < mmq; i += 64) ((uint4*)mm)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = lane; i < nwords; i += 64) { bitsIni[i] = 0; bitsMin[i] = 0; }
   }
   __syncthreads();
+
+  // ---- 2. quick rejection, 4 columns x 2 rows per lane ------------------------
+  const int ini = plan->ini_th, mn = plan->min_th;
+  const int tlow = min(ini, mn);
+  const uint32_t tt = (uint32_t)tlow * 0x00010001u;
+  const int ngx = (cw + 3) >> 2, nry = (ch + 1) >> 1;
+  const int ntask = ngx * nry;
+  const float rngx = 1.0f / (float)ngx;
+  int qn = 0;
+  for (int base = 0; base < ntask; base += 64) {
+    const int tsk = base + lane;
+    uint32_t flags = 0;
+    int x = 0, y = 0;
+    if (tsk < ntask) {
+      const int r = (int)(((float)tsk + 0.5f) * rngx);
+      x = (tsk - r * ngx) * 4;
+      y = r * 2;
+      uint32_t R[8][3];
+      const uint8_t* wp = tile + y * TS + x;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t* rp = (const uint32_t*)(wp + i * TS);
+        R[i][0] = rp[0]; R[i][1] = rp[1]; R[i][2] = rp[2];
+      }
+      const uint32_t e0 = quick_pair<3, 4>(R, tt);  // row y,   columns x, x+2
+      const uint32_t o0 = quick_pair<3, 5>(R, tt);  // row y,   columns x+1, x+3
+      const uint32_t e1 = quick_pair<4, 4>(R, tt);  // row y+1
+      const uint32_t o1 = quick_pair<4, 5>(R, tt);
+      flags |= ((int)(short)(e0 & 0xFFFF) > 0) ? 1u : 0u;
+      flags |= ((int)(short)(o0 & 0xFFFF) > 0) ? 2u : 0u;
+      flags |= ((int)e0 >> 16 > 0) ? 4u : 0u;
+      flags |= ((int)o0 >> 16 > 0) ? 8u : 0u;
+      flags |= ((int)(short)(e1 & 0xFFFF) > 0) ? 16u : 0u;
+      flags |= ((int)(short)(o1 & 0xFFFF) > 0) ? 32u : 0u;
+      flags |= ((int)e1 >> 16 > 0) ? 64u : 0u;
+      flags |= ((int)o1 >> 16 > 0) ? 128u : 0u;
+      // pixels outside the cell
+      uint32_t colmask = (x + 4 <= cw) ? 0xFu : ((1u << (cw - x)) - 1u);
+      uint32_t valid = colmask | ((y + 1 < ch) ? (colmask << 4) : 0u);
+      flags &= valid;
+    }
+    const int c = __popc(flags);
+    const int inc = wave_incl_scan(c);
+    int qpos = qn + inc - c;
+    while (flags) {
+      const int b = __ffs(flags) - 1;
+      flags &= flags - 1;
+      queue[qpos++] = (uint16_t)(((y + (b >> 2)) << 7) | (x + (b & 3)));
+    }
+    qn += __shfl(inc, 63, 64);
+  }
+  __syncthreads();
+
+  // ---- 3. exact m for the survivors -------------------------------------------
+  for (int qi = lane; qi < qn; qi += 64) {
+    const int id = queue[qi];
+    const int x = id & 127, y = id >> 7;
+    mm[(y + 1) * TS + x + 4] = (uint8_t)fast_m<TS>(tile + (y + 3) * TS + x + 4);
+  }
+  __syncthreads();
+
+  // ---- 4. suppression inside the cell, both thresholds -------------------------
+  int anyIni = 0;
+  for (int qi = lane; qi < qn; qi += 64) {
+    const int id = queue[qi];
+    const int x = id & 127, y = id >> 7;
+    const uint8_t* q = mm + (y + 1) * TS + x + 4;
+    const int m = q[0];
+    if (m > tlow) {
+      const bool isMax = m > q[-1] && m > q[1] && m > q[-TS - 1] && m > q[-TS] && m > q[-TS + 1] &&
+                         m > q[TS - 1] && m > q[TS] && m > q[TS + 1];
+      if (isMax) {
+        const int p = y * cw + x;
+        if (m > ini) { atomicOr(&bitsIni[p >> 5], 1u << (p & 31)); anyIni = 1; }
+        if (m > mn) atomicOr(&bitsMin[p >> 5], 1u << (p & 31));
+      }
+    }
+  }
+  const bool useIni = __syncthreads_or(anyIni) != 0;
+  const uint32_t* bits = useIni ? bitsIni : bitsMin;
+
+  // ---- 5. ordered output ---------------------------------------------------------
   uint32_t* out = cand + (size_t)f * plan->cand_frame + L.cand_off + (size_t)cell * L.cand_cap_cell;
-  for (int cidx = wave; cidx < nchunks; cidx += 4) {
-    const int p = cidx * 64 + lane;
-    const int m = p < np ? selv[p] : 0;
-    const bool keep = m > thr;
-    const unsigned long long mask = __ballot(keep);
-    if (keep) {
+  const float rcw = 1.0f / (float)cw;
+  int running = 0;
+  for (int wbase = 0; wbase < nwords; wbase += 64) {
+    const int wi = wbase + lane;
+    uint32_t word = wi < nwords ? bits[wi] : 0u;
+    const int c = __popc(word);
+    const int inc = wave_incl_scan(c);
+    int o = running + inc - c;
+    while (word) {
+      const int b = __ffs(word) - 1;
+      word &= word - 1;
+      const int p = wi * 32 + b;
       const int y = (int)(((float)p + 0.5f) * rcw);
       const int x = p - y * cw;
-      const uint32_t key = (uint32_t)(X0 + x - ORBX_DET_ORG) | ((uint32_t)(Y0 + y - ORBX_DET_ORG) << 12) |
-                           ((uint32_t)(m - 1) << 24);
-      out[chunkCnt[cidx] + mbcnt64(mask)] = key;
+      const int m = mm[(y + 1) * TS + x + 4];
+      out[o++] = (uint32_t)(X0 + x - ORBX_DET_ORG) | ((uint32_t)(Y0 + y - ORBX_DET_ORG) << 12) |
+                 ((uint32_t)(m - 1) << 24);
     }
+    running += __shfl(inc, 63, 64);
   }
+  if (lane == 0) cellCount[(size_t)f * plan->cells_per_frame + cellg] = running;
 }
 
 // ---------------------------------------------------------------------------
@@ -672,52 +799,74 @@ __global__ __launch_bounds__(256) void k_assemble(const Plan* __restrict__ plan,
 // K6: 7x7 Gaussian blur, sigma 2, OpenCV's 8.8 fixed-point kernel
 // {18,34,48,56,48,34,18}: 16-bit row sums, (sum + 2^15) >> 16 after the
 // column pass.  The source is the padded pyramid plane, whose own border is
-// the REFLECT_101 extension the blur needs.  Tile = 64 x 32 output pixels.
+// the REFLECT_101 extension the blur needs.
+//
+// A lane owns 4 adjacent columns and walks down a band of rows.  Per input
+// row it reads 12 aligned bytes (the 10 it needs start at padded column
+// x0 + 16, a multiple of 4), forms the 4 horizontal sums in registers and
+// adds them, weighted, into 7 rolling column accumulators; the accumulator
+// that has seen all 7 rows is rounded and stored as one dword.  No LDS.
+// Block = 4 waves stacked vertically; a wave covers 256 columns x BLUR_BAND rows.
 // ---------------------------------------------------------------------------
-#define BLUR_TW 64
-#define BLUR_TH 32
+#define BLUR_BAND 64
 __global__ __launch_bounds__(256) void k_blur(const Plan* __restrict__ plan,
                                               const uint8_t* __restrict__ pyr,
                                               uint8_t* __restrict__ blur) {
-  __shared__ uint8_t sIn[(BLUR_TH + 6) * (BLUR_TW + 8)];
-  __shared__ uint16_t sH[(BLUR_TH + 6) * BLUR_TW];
-  const int tid = threadIdx.x, f = blockIdx.y;
+  const int f = blockIdx.y;
   const int tg = blockIdx.x;
   int l = 0;
   while (l + 1 < plan->nlevels && tg >= plan->lv[l + 1].tile_first) ++l;
   const LevelDesc& L = plan->lv[l];
   const int t = tg - L.tile_first;
   const int tyi = t / L.tiles_x, txi = t - tyi * L.tiles_x;
-  const int x0 = txi * BLUR_TW, y0 = tyi * BLUR_TH;
-  const int SW = BLUR_TW + 8;
-  // source rows y0-3 .. y0+TH+2, cols x0-3 .. x0+TW+2 (level coords) -> padded +19
-  const uint8_t* src = pyr + L.pyr_off + (size_t)f * L.pyr_plane +
-                       (size_t)(y0 - 3 + ORBX_EDGE) * L.pstride + (x0 - 3 + ORBX_EDGE);
-  const int maxc = L.pstride - (x0 - 3 + ORBX_EDGE);      // readable columns
-  const int maxr = L.prows - (y0 - 3 + ORBX_EDGE);        // readable rows
-  for (int i = tid; i < (BLUR_TH + 6) * (BLUR_TW + 6); i += 256) {
-    const int r = i / (BLUR_TW + 6), c = i - r * (BLUR_TW + 6);
-    uint8_t v = 0;
-    if (r < maxr && c < maxc) v = src[(size_t)r * L.pstride + c];
-    sIn[r * SW + c] = v;
-  }
-  __syncthreads();
-  for (int i = tid; i < (BLUR_TH + 6) * BLUR_TW; i += 256) {
-    const int r = i >> 6, c = i & 63;
-    const uint8_t* p = &sIn[r * SW + c];
-    const int s = 18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 48 * (p[2] + p[4]) + 56 * p[3];
-    sH[i] = (uint16_t)s;
-  }
-  __syncthreads();
-  uint8_t* dst = blur + L.blur_off + (size_t)f * L.blur_plane;
-  for (int i = tid; i < BLUR_TH * BLUR_TW; i += 256) {
-    const int r = i >> 6, c = i & 63;
-    const int x = x0 + c, y = y0 + r;
-    if (x < L.w && y < L.h) {
-      const uint16_t* p = &sH[r * BLUR_TW + c];
-      const uint32_t s = 18u * (p[0] + p[6 * BLUR_TW]) + 34u * (p[BLUR_TW] + p[5 * BLUR_TW]) +
-                         48u * (p[2 * BLUR_TW] + p[4 * BLUR_TW]) + 56u * p[3 * BLUR_TW];
-      dst[(size_t)y * L.bstride + x] = (uint8_t)((s + 32768u) >> 16);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int x0 = txi * 256 + lane * 4;
+  const int y0 = (tyi * 4 + wave) * BLUR_BAND;
+  if (x0 >= L.w || y0 >= L.h) return;
+  const int nout = min(BLUR_BAND, L.h - y0);
+  const int nin = nout + 6;
+  // input row i of the band = level row y0 - 3 + i = padded row y0 + 16 + i
+  const uint8_t* src = pyr + L.pyr_off + (size_t)f * L.pyr_plane + (size_t)(y0 + 16) * L.pstride + (x0 + 16);
+  uint8_t* dst = blur + L.blur_off + (size_t)f * L.blur_plane + (size_t)y0 * L.bstride + x0;
+  const int ps = L.pstride, bs = L.bstride;
+  uint32_t acc[7][4];
+#pragma unroll
+  for (int j = 0; j < 7; ++j)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[j][c] = 0;
+  const uint32_t K[7] = {18, 34, 48, 56, 48, 34, 18};
+  for (int i0 = 0; i0 < nin; i0 += 7) {
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+      const int i = i0 + s;
+      if (i < nin) {
+        const uint32_t* rp = (const uint32_t*)(src + (size_t)i * ps);
+        const uint32_t d0 = rp[0], d1 = rp[1], d2 = rp[2];
+        uint32_t b[10];
+        b[0] = d0 & 0xFF; b[1] = (d0 >> 8) & 0xFF; b[2] = (d0 >> 16) & 0xFF; b[3] = d0 >> 24;
+        b[4] = d1 & 0xFF; b[5] = (d1 >> 8) & 0xFF; b[6] = (d1 >> 16) & 0xFF; b[7] = d1 >> 24;
+        b[8] = d2 & 0xFF; b[9] = (d2 >> 8) & 0xFF;
+        uint32_t h[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          h[c] = 18u * (b[c] + b[c + 6]) + 34u * (b[c + 1] + b[c + 5]) + 48u * (b[c + 2] + b[c + 4]) + 56u * b[c + 3];
+        // input row i feeds outputs o = i - j (j = 0..6) with weight K[j]; slot of o is o mod 7
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+          const int slot = (s - j + 7) % 7;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[slot][c] += K[j] * h[c];
+        }
+        // output o = i - 6 is complete; its slot is (s + 1) mod 7
+        const int done = (s + 1) % 7;
+        if (i >= 6) {
+          const uint32_t o0 = (acc[done][0] + 32768u) >> 16, o1 = (acc[done][1] + 32768u) >> 16,
+                         o2 = (acc[done][2] + 32768u) >> 16, o3 = (acc[done][3] + 32768u) >> 16;
+          *(uint32_t*)(dst + (size_t)(i - 6) * bs) = o0 | (o1 << 8) | (o2 << 16) | (o3 << 24);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[done][c] = 0;
+      }
     }
   }
 }
@@ -842,10 +991,22 @@ void launch_pyramid(const Plan& hp, const uint8_t* d_img, int istride, size_t if
   }
 }
 
+size_t fast_lds_bytes(const Plan& hp, int ts) {
+  return (size_t)(hp.fast_tile_rows + hp.fast_mm_rows) * ts + (size_t)hp.fast_qcap * 2 +
+         (size_t)hp.fast_words * 8 + 16;
+}
+
 void launch_fast(const Plan& hp, const Plan* dp, const uint8_t* d_pyr, uint32_t* d_cand,
                  int* d_cellCount, int nframes, hipStream_t s) {
   dim3 grid(hp.cells_per_frame, nframes);
-  hipLaunchKernelGGL(k_fast_cells, grid, dim3(256), 0, s, dp, d_pyr, d_cand, d_cellCount);
+  const int ts = hp.fast_ts;
+  const size_t lds = fast_lds_bytes(hp, ts);
+  if (ts == 48)
+    hipLaunchKernelGGL(k_fast_cells<48>, grid, dim3(64), lds, s, dp, d_pyr, d_cand, d_cellCount);
+  else if (ts == 64)
+    hipLaunchKernelGGL(k_fast_cells<64>, grid, dim3(64), lds, s, dp, d_pyr, d_cand, d_cellCount);
+  else
+    hipLaunchKernelGGL(k_fast_cells<80>, grid, dim3(64), lds, s, dp, d_pyr, d_cand, d_cellCount);
 }
 
 size_t octree_lds_bytes(const Plan& hp) {

@@ -61,6 +61,9 @@ struct Plan {
   uint32_t flat_frame;   // uint32 per frame in each flat key buffer
   int sel_frame;         // selected-key slots per frame (all levels)
   int kp_cap;            // keypoint slots per frame in the outputs (= sel_frame)
+  // k_fast_cells LDS geometry (max over levels): row stride, tile rows, m-map rows,
+  // survivor queue entries, bit-mask words
+  int fast_ts, fast_tile_rows, fast_mm_rows, fast_qcap, fast_words;
   int oct_nodes_cap;     // quadtree node slots (max over levels)
   int oct_cells_max;     // max cells in one level
   int umax[16];          // circular patch row half-widths (extractor.cc:448-462)
