@@ -36,6 +36,7 @@ int octree_set_lds_limit(const Plan& hp);
 using orbx::LevelDesc;
 using orbx::Plan;
 using orbx::Tap;
+using orbx::ColRec;
 using orbx::WorkItem;
 
 namespace {
@@ -83,7 +84,7 @@ struct orbx_extractor {
   bool planned = false;
   Plan hp;
   Plan* dp = nullptr;
-  std::vector<Tap*> d_taps;
+  std::vector<void*> d_taps;
 
   uint8_t* d_img = nullptr;   // staging for host-image entry points
   uint8_t* d_pyr = nullptr;
@@ -159,7 +160,7 @@ void orbx_extractor::freePlan() {
   if (!planned) return;
   (void)hipSetDevice(device);
   (void)hipStreamSynchronize(stream);
-  for (Tap* t : d_taps) (void)hipFree(t);
+  for (void* t : d_taps) (void)hipFree(t);
   d_taps.clear();
   void* bufs[] = {dp, d_img, d_pyr, d_blur, d_cand, d_cellCount, d_flatA, d_flatB, d_sel, d_selCount,
                   d_kps, d_desc, d_work, d_n, d_mono};
@@ -296,21 +297,75 @@ int orbx_extractor::ensurePlan(int W, int H) {
   if (orbx::octree_set_lds_limit(hp) != 0) return ORBX_ERR_UNSUPPORTED;
 
   planned = true;  // from here on freePlan() releases whatever was allocated
-  // resize tap tables
+  // resize tap tables + tiling records
+  size_t resizeLds = 0;
   for (int l = 1; l < nl; ++l) {
     std::vector<Tap> tx, ty;
     build_taps(hp.lv[l - 1].w, hp.lv[l].w, true, tx);
     build_taps(hp.lv[l - 1].h, hp.lv[l].h, false, ty);
-    Tap *dx = nullptr, *dy = nullptr;
-    HIP_TRY(hipMalloc((void**)&dx, tx.size() * sizeof(Tap)));
-    d_taps.push_back(dx);
-    HIP_TRY(hipMalloc((void**)&dy, ty.size() * sizeof(Tap)));
-    d_taps.push_back(dy);
+    LevelDesc& L = hp.lv[l];
+    const int pw = L.w + 2 * ORBX_EDGE, ph = L.prows;
+    const int ncol = L.pstride / 4;
+    std::vector<ColRec> cr(ncol);
+    for (int c = 0; c < ncol; ++c) {
+      ColRec r;
+      std::memset(&r, 0, sizeof(r));
+      bool ok = 4 * c + 3 < pw;
+      if (ok) {
+        const int sxa = tx[4 * c].s0;
+        r.sxa = (uint16_t)sxa;
+        for (int k = 0; k < 4 && ok; ++k) {
+          const Tap& t = tx[4 * c + k];
+          const int d = (int)t.s0 - sxa;
+          ok = d >= 0 && d <= 6 && (t.s1 == t.s0 + 1 || (t.s1 == t.s0 && t.w1 == 0)) &&
+               t.w0 + t.w1 == 2048 && t.w1 >= 0;
+          r.deltas |= (uint16_t)(d << (3 * k));
+          r.w1[k] = (uint16_t)t.w1;
+        }
+      }
+      if (ok) r.deltas |= 0x8000; else r.deltas = 0;
+      cr[c] = r;
+    }
+    const int nbx = (L.pstride + 255) / 256, nby = (ph + 15) / 16;
+    std::vector<uint16_t> xb(2 * nbx), yb(2 * nby);
+    int spanx = 0, spany = 0;
+    for (int b = 0; b < nbx; ++b) {
+      int lo = 1 << 30, hi = -1;
+      for (int p = 256 * b; p < std::min(256 * b + 256, pw); ++p) {
+        lo = std::min(lo, (int)tx[p].s0);
+        hi = std::max(hi, (int)tx[p].s1);
+      }
+      if (hi < 0) { lo = 0; hi = 0; }
+      xb[2 * b] = (uint16_t)lo; xb[2 * b + 1] = (uint16_t)hi;
+      spanx = std::max(spanx, hi - lo + 1);
+    }
+    for (int b = 0; b < nby; ++b) {
+      int lo = 1 << 30, hi = -1;
+      for (int p = 16 * b; p < std::min(16 * b + 16, ph); ++p) {
+        lo = std::min(lo, (int)ty[p].s0);
+        hi = std::max(hi, (int)ty[p].s1);
+      }
+      yb[2 * b] = (uint16_t)lo; yb[2 * b + 1] = (uint16_t)hi;
+      spany = std::max(spany, hi - lo + 1);
+    }
+    L.rs_ls = round_up(spanx + 3 + 12, 4);   // phase (<=3) + span + 3-dword window overrun
+    L.rs_rows = spany;
+    resizeLds = std::max(resizeLds, (size_t)L.rs_ls * L.rs_rows);
+    void *dx = nullptr, *dy = nullptr, *dc = nullptr, *dxb = nullptr, *dyb = nullptr;
+    HIP_TRY(hipMalloc(&dx, tx.size() * sizeof(Tap))); d_taps.push_back(dx);
+    HIP_TRY(hipMalloc(&dy, ty.size() * sizeof(Tap))); d_taps.push_back(dy);
+    HIP_TRY(hipMalloc(&dc, cr.size() * sizeof(ColRec))); d_taps.push_back(dc);
+    HIP_TRY(hipMalloc(&dxb, xb.size() * 2)); d_taps.push_back(dxb);
+    HIP_TRY(hipMalloc(&dyb, yb.size() * 2)); d_taps.push_back(dyb);
     HIP_TRY(hipMemcpy(dx, tx.data(), tx.size() * sizeof(Tap), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dy, ty.data(), ty.size() * sizeof(Tap), hipMemcpyHostToDevice));
-    hp.lv[l].xtab = dx;
-    hp.lv[l].ytab = dy;
+    HIP_TRY(hipMemcpy(dc, cr.data(), cr.size() * sizeof(ColRec), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dxb, xb.data(), xb.size() * 2, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dyb, yb.data(), yb.size() * 2, hipMemcpyHostToDevice));
+    L.xtab = (const Tap*)dx; L.ytab = (const Tap*)dy; L.colrec = (const ColRec*)dc;
+    L.xblk = (const uint16_t*)dxb; L.yblk = (const uint16_t*)dyb;
   }
+  if (resizeLds + 64 > 60 * 1024) return ORBX_ERR_UNSUPPORTED;
   HIP_TRY(hipMalloc((void**)&dp, sizeof(Plan)));
   HIP_TRY(hipMemcpy(dp, &hp, sizeof(Plan), hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc((void**)&d_img, (size_t)B * W * H));

@@ -81,34 +81,108 @@ __global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t* __restrict__ 
 // K1b: level l = cv::resize(level l-1, INTER_LINEAR) + REFLECT_101 border.
 // The tap tables are indexed by padded destination coordinates, so border
 // pixels are produced by the same code as interior ones.
+//
+// A block produces a 256 x 16 tile of the padded destination plane.  The
+// source window the tile touches is staged in LDS with coalesced dword loads;
+// a lane then owns one destination dword column (4 pixels) over 4 rows.
+// Interior columns take the fast path: the 8 source bytes that hold all taps
+// of the 4 pixels are re-based with v_alignbyte and each pixel's tap pair is
+// picked with one v_perm_b32.  Columns in the reflected border or at the
+// clamped right edge use the per-pixel tap table.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pyr_resize(const uint8_t* __restrict__ src, int sstride,
                                                     size_t splane, uint8_t* __restrict__ dst,
                                                     int pstride, int prows, size_t dplane, int pw,
                                                     const Tap* __restrict__ xtab,
-                                                    const Tap* __restrict__ ytab) {
-  const int c = blockIdx.x * 64 + threadIdx.x;
-  const int py = blockIdx.y * 4 + threadIdx.y;
+                                                    const Tap* __restrict__ ytab,
+                                                    const ColRec* __restrict__ colrec,
+                                                    const uint16_t* __restrict__ xblk,
+                                                    const uint16_t* __restrict__ yblk, int LS) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  const int tid = threadIdx.y * 64 + threadIdx.x;
   const int f = blockIdx.z;
-  if (c * 4 >= pstride || py >= prows) return;
-  const Tap ty = ytab[py];
-  const uint8_t* roi = src + (size_t)f * splane + (size_t)ORBX_EDGE * sstride + ORBX_EDGE;
-  const uint8_t* r0 = roi + (size_t)ty.s0 * sstride;
-  const uint8_t* r1 = roi + (size_t)ty.s1 * sstride;
-  const int b0 = ty.w0, b1 = ty.w1;
-  uint32_t out = 0;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int px = 4 * c + k;
-    if (px < pw) {
-      const Tap tx = xtab[px];
-      const int h0 = (int)r0[tx.s0] * tx.w0 + (int)r0[tx.s1] * tx.w1;
-      const int h1 = (int)r1[tx.s0] * tx.w0 + (int)r1[tx.s1] * tx.w1;
-      const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-      out |= (uint32_t)(v & 0xFF) << (8 * k);
+  const int sxlo = xblk[2 * blockIdx.x], sxhi = xblk[2 * blockIdx.x + 1];
+  const int sylo = yblk[2 * blockIdx.y], syhi = yblk[2 * blockIdx.y + 1];
+  // source ROI starts 19 rows / 19 bytes into the (64-byte aligned) plane
+  const int phase = (ORBX_EDGE + sxlo) & 3;
+  const uint8_t* g0 = src + (size_t)f * splane + (size_t)(ORBX_EDGE + sylo) * sstride + (ORBX_EDGE + sxlo - phase);
+  const int nd = (phase + (sxhi - sxlo + 1) + 3 + 8) >> 2;   // dwords per row incl. window overrun
+  const int nr = syhi - sylo + 1;
+  {
+    const int total = nr * nd;
+    const float rnd = 1.0f / (float)nd;
+    for (int i = tid; i < total; i += 256) {
+      const int r = (int)(((float)i + 0.5f) * rnd);
+      const int n = i - r * nd;
+      *(uint32_t*)(smem + r * LS + 4 * n) = *((const uint32_t*)(g0 + (size_t)r * sstride) + n);
     }
   }
-  *(uint32_t*)(dst + (size_t)f * dplane + (size_t)py * pstride + 4 * c) = out;
+  __syncthreads();
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c * 4 >= pstride) return;
+  const ColRec cr = colrec[c];
+  uint8_t* dcol = dst + (size_t)f * dplane + 4 * c;
+  const int py0 = blockIdx.y * 16 + threadIdx.y * 4;
+  if (cr.deltas & 0x8000) {
+    const int cb = phase + ((int)cr.sxa - sxlo);
+    const int ad = (cb >> 2) * 4, sh = cb & 3;
+    uint32_t sel[4];
+    int w0[4], w1[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t d = (cr.deltas >> (3 * k)) & 7u;
+      sel[k] = 0x0c000c00u | d | ((d + 1u) << 16);
+      w1[k] = cr.w1[k];
+      w0[k] = 2048 - w1[k];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int py = py0 + r;
+      if (py < prows) {
+        const Tap ty = ytab[py];
+        const uint32_t* p0 = (const uint32_t*)(smem + ((int)ty.s0 - sylo) * LS + ad);
+        const uint32_t* p1 = (const uint32_t*)(smem + ((int)ty.s1 - sylo) * LS + ad);
+        const uint32_t a0 = p0[0], a1 = p0[1], a2 = p0[2];
+        const uint32_t b0 = p1[0], b1 = p1[1], b2 = p1[2];
+        const uint32_t alo = __builtin_amdgcn_alignbyte(a1, a0, sh), ahi = __builtin_amdgcn_alignbyte(a2, a1, sh);
+        const uint32_t blo = __builtin_amdgcn_alignbyte(b1, b0, sh), bhi = __builtin_amdgcn_alignbyte(b2, b1, sh);
+        const int wy0 = ty.w0, wy1 = ty.w1;
+        uint32_t out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint32_t pa = __builtin_amdgcn_perm(ahi, alo, sel[k]);
+          const uint32_t pb = __builtin_amdgcn_perm(bhi, blo, sel[k]);
+          const int h0 = (int)(pa & 0xFFFF) * w0[k] + (int)(pa >> 16) * w1[k];
+          const int h1 = (int)(pb & 0xFFFF) * w0[k] + (int)(pb >> 16) * w1[k];
+          const int v = (((wy0 * (h0 >> 4)) >> 16) + ((wy1 * (h1 >> 4)) >> 16) + 2) >> 2;
+          out |= (uint32_t)(v & 0xFF) << (8 * k);
+        }
+        *(uint32_t*)(dcol + (size_t)py * pstride) = out;
+      }
+    }
+  } else {
+#pragma unroll 1
+    for (int r = 0; r < 4; ++r) {
+      const int py = py0 + r;
+      if (py < prows) {
+        const Tap ty = ytab[py];
+        const uint8_t* r0 = smem + ((int)ty.s0 - sylo) * LS + phase - sxlo;
+        const uint8_t* r1 = smem + ((int)ty.s1 - sylo) * LS + phase - sxlo;
+        uint32_t out = 0;
+        for (int k = 0; k < 4; ++k) {
+          const int px = 4 * c + k;
+          if (px < pw) {
+            const Tap tx = xtab[px];
+            const int h0 = (int)r0[tx.s0] * tx.w0 + (int)r0[tx.s1] * tx.w1;
+            const int h1 = (int)r1[tx.s0] * tx.w0 + (int)r1[tx.s1] * tx.w1;
+            const int v = ((((int)ty.w0 * (h0 >> 4)) >> 16) + (((int)ty.w1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            out |= (uint32_t)(v & 0xFF) << (8 * k);
+          }
+        }
+        *(uint32_t*)(dcol + (size_t)py * pstride) = out;
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -873,9 +947,9 @@ __global__ __launch_bounds__(256) void k_blur(const Plan* __restrict__ plan,
 
 // ---------------------------------------------------------------------------
 // K5 + K7: orientation by intensity centroid, then the 256-bit rotated BRIEF
-// descriptor.  One wave per keypoint.
+// descriptor.
 // ---------------------------------------------------------------------------
-__constant__ int8_t c_pattern[256 * 4] = {
+__constant__ __attribute__((aligned(16))) int8_t c_pattern[256 * 4] = {
 #include "orb_pattern_31.inc"
 };
 
@@ -903,6 +977,10 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
   return a;
 }
 
+// 16 lanes per keypoint, 4 keypoints per wave, 16 per block.
+//  * moments: lane j of a group owns patch columns u = 2j-15 and 2j-14 and walks the
+//    31 rows (62 independent byte loads in flight per lane);
+//  * descriptor: lane j evaluates tests 16j .. 16j+15 = descriptor bytes 2j, 2j+1.
 __global__ __launch_bounds__(256) void k_orient_describe(const Plan* __restrict__ plan,
                                                          const uint8_t* __restrict__ pyr,
                                                          const uint8_t* __restrict__ blur,
@@ -912,61 +990,72 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Plan* __restrict_
                                                          uint8_t* __restrict__ desc) {
   const int f = blockIdx.y;
   const int lane = threadIdx.x & 63;
-  const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (k >= nOut[f]) return;
-  const WorkItem wi = work[(size_t)f * plan->kp_cap + k];
+  const int g = lane >> 4, j16 = lane & 15;
+  const int n = nOut[f];
+  const int kbase = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+  if (kbase >= n) return;
+  const int k = kbase + g;
+  const bool valid = k < n;
+  const WorkItem wi = work[(size_t)f * plan->kp_cap + (valid ? k : n - 1)];
   const LevelDesc& L = plan->lv[wi.level];
   const int cx = wi.xy & 0xFFFF, cy = wi.xy >> 16;
+  const int ps = L.pstride, bs = L.bstride;
 
   // ---- IC_Angle on the un-blurred level (extractor.cc:75-99) ----------------
-  // lanes: u = (lane & 31) - 15 (lane 31 of each half idles), half 0 takes
-  // rows v = -15..0, half 1 rows v = 1..15
   const uint8_t* center = pyr + L.pyr_off + (size_t)f * L.pyr_plane +
-                          (size_t)(cy + ORBX_EDGE) * L.pstride + (cx + ORBX_EDGE);
-  const int u = (lane & 31) - 15;
-  const int au = u < 0 ? -u : u;
-  const int half = lane >> 5;
+                          (size_t)(cy + ORBX_EDGE) * ps + (cx + ORBX_EDGE);
+  const int u0 = 2 * j16 - 15, u1 = u0 + 1;
+  const int au0 = u0 < 0 ? -u0 : u0, au1 = u1 < 0 ? -u1 : u1;
+  int um[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) um[i] = plan->umax[i];
   int m10 = 0, m01 = 0;
-  if (u <= 15) {
-    const int vbeg = half ? 1 : -15, vend = half ? 15 : 0;
-    for (int v = vbeg; v <= vend; ++v) {
-      const int av = v < 0 ? -v : v;
-      if (au <= plan->umax[av]) {
-        const int val = center[v * L.pstride + u];
-        m10 += u * val;
-        m01 += v * val;
-      }
-    }
+#pragma unroll
+  for (int v = -15; v <= 15; ++v) {
+    const int lim = um[v < 0 ? -v : v];
+    const uint8_t* rp = center + v * ps;
+    const int a = au0 <= lim ? (int)rp[u0] : 0;
+    const int b = au1 <= lim ? (int)rp[u1] : 0;   // u1 = 16 never passes (lim <= 15)
+    m10 += u0 * a + u1 * b;
+    m01 += v * (a + b);
   }
-  m10 = wave_sum(m10);
-  m01 = wave_sum(m01);
+#pragma unroll
+  for (int d = 8; d >= 1; d >>= 1) {
+    m10 += __shfl_xor(m10, d, 64);
+    m01 += __shfl_xor(m01, d, 64);
+  }
   const float angle = fast_atan2_deg((float)m01, (float)m10);
 
   // ---- steered BRIEF on the blurred level (extractor.cc:102-145) ------------
   const float factorPI = (float)(3.1415926535897932384626433832795 / 180.0);
   const float rad = __fmul_rn(angle, factorPI);
   const float a = (float)cos((double)rad), b = (float)sin((double)rad);
-  const uint8_t* bc = blur + L.blur_off + (size_t)f * L.blur_plane + (size_t)cy * L.bstride + cx;
-  const int bs = L.bstride;
-  unsigned long long bits[4];
+  const uint8_t* bc = blur + L.blur_off + (size_t)f * L.blur_plane + (size_t)cy * bs + cx;
+  const uint4* pp = (const uint4*)(c_pattern + 64 * j16);
+  uint32_t bits = 0;
 #pragma unroll
-  for (int pass = 0; pass < 4; ++pass) {
-    const int t = pass * 64 + lane;
-    const float x0 = (float)c_pattern[4 * t + 0], y0 = (float)c_pattern[4 * t + 1];
-    const float x1 = (float)c_pattern[4 * t + 2], y1 = (float)c_pattern[4 * t + 3];
-    const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
-    const int q0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
-    const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
-    const int q1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-    const int t0 = bc[r0 * bs + q0];
-    const int t1 = bc[r1 * bs + q1];
-    bits[pass] = __ballot(t0 < t1);
+  for (int q = 0; q < 4; ++q) {
+    const uint4 w4 = pp[q];
+    const uint32_t ws[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t w = ws[e];
+      const float x0 = (float)(int8_t)(w & 0xFF), y0 = (float)(int8_t)((w >> 8) & 0xFF);
+      const float x1 = (float)(int8_t)((w >> 16) & 0xFF), y1 = (float)(int8_t)(w >> 24);
+      const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
+      const int q0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
+      const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
+      const int q1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
+      const int t0 = bc[r0 * bs + q0];
+      const int t1 = bc[r1 * bs + q1];
+      bits |= (t0 < t1 ? 1u : 0u) << (q * 4 + e);
+    }
   }
-  if (lane < 4) {
-    unsigned long long w = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
-    *(unsigned long long*)(desc + ((size_t)f * plan->kp_cap + wi.dst) * 32 + 8 * lane) = w;
+  if (valid) {
+    const size_t slot = (size_t)f * plan->kp_cap + wi.dst;
+    *(uint16_t*)(desc + slot * 32 + 2 * j16) = (uint16_t)bits;
+    if (j16 == 0) kps[slot * 7 + 3] = angle;
   }
-  if (lane == 0) kps[((size_t)f * plan->kp_cap + wi.dst) * 7 + 3] = angle;
 }
 
 // ---------------------------------------------------------------------------
@@ -984,10 +1073,10 @@ void launch_pyramid(const Plan& hp, const uint8_t* d_img, int istride, size_t if
   for (int l = 1; l < hp.nlevels; ++l) {
     const LevelDesc& S = hp.lv[l - 1];
     const LevelDesc& L = hp.lv[l];
-    dim3 grid((L.pstride / 4 + 63) / 64, (L.prows + 3) / 4, nframes);
-    hipLaunchKernelGGL(k_pyr_resize, grid, blk, 0, s, d_pyr + S.pyr_off, S.pstride, S.pyr_plane,
-                       d_pyr + L.pyr_off, L.pstride, L.prows, L.pyr_plane, L.w + 2 * ORBX_EDGE,
-                       L.xtab, L.ytab);
+    dim3 grid((L.pstride + 255) / 256, (L.prows + 15) / 16, nframes);
+    hipLaunchKernelGGL(k_pyr_resize, grid, blk, (size_t)L.rs_ls * L.rs_rows + 16, s, d_pyr + S.pyr_off,
+                       S.pstride, S.pyr_plane, d_pyr + L.pyr_off, L.pstride, L.prows, L.pyr_plane,
+                       L.w + 2 * ORBX_EDGE, L.xtab, L.ytab, L.colrec, L.xblk, L.yblk, L.rs_ls);
   }
 }
 
@@ -1039,7 +1128,7 @@ void launch_blur(const Plan& hp, const Plan* dp, const uint8_t* d_pyr, uint8_t* 
 void launch_describe(const Plan& hp, const Plan* dp, const uint8_t* d_pyr, const uint8_t* d_blur,
                      const WorkItem* d_work, const int* d_n, float* d_kps, uint8_t* d_desc,
                      int nframes, hipStream_t s) {
-  dim3 grid((hp.kp_cap + 3) / 4, nframes);
+  dim3 grid((hp.kp_cap + 15) / 16, nframes);
   hipLaunchKernelGGL(k_orient_describe, grid, dim3(256), 0, s, dp, d_pyr, d_blur, d_work, d_n, d_kps,
                      d_desc);
 }

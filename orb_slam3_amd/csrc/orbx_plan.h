@@ -24,6 +24,15 @@ struct Tap {
   int16_t w0, w1;
 };
 
+// Per destination dword column (4 padded pixels) of a resized level: where its
+// source bytes start and how the 4 pixels pick from the 8 bytes that follow.
+struct ColRec {
+  uint16_t sxa;      // source x of pixel 0's left tap
+  uint16_t deltas;   // 3 bits per pixel: left tap - sxa (0..6); bit 15: fast path valid
+  uint16_t w1[4];    // right-tap weight per pixel (left = 2048 - w1)
+  uint16_t pad[2];
+};
+
 struct LevelDesc {
   int w, h;              // level image size
   int pstride, prows;    // padded plane: row stride (bytes, multiple of 64), rows = h + 38
@@ -49,6 +58,12 @@ struct LevelDesc {
   int patch_size;        // (int)(31 * scale)
   const Tap* xtab;       // [w + 38]
   const Tap* ytab;       // [h + 38]
+  // k_pyr_resize tiling: 256 x 16 destination tiles, source window staged in LDS
+  const ColRec* colrec;  // [pstride / 4]
+  const uint16_t* xblk;  // per 256-column block: lowest / highest source x touched
+  const uint16_t* yblk;  // per 16-row block: lowest / highest source y touched
+  int rs_ls;             // LDS row stride (bytes) for this level's source windows
+  int rs_rows;           // LDS rows
 };
 
 struct Plan {
