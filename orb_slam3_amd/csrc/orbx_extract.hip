@@ -45,6 +45,12 @@ __device__ __forceinline__ int wave_sum(int v) {
   return v;
 }
 
+// a.lo*b.lo + a.hi*b.hi + c on unsigned 16-bit halves (v_dot2_u32_u16)
+typedef unsigned short dot_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c) {
+  return __builtin_amdgcn_udot2(__builtin_bit_cast(dot_us2, a), __builtin_bit_cast(dot_us2, b), c, false);
+}
+
 __device__ __forceinline__ int reflect101(int i, int n) {
   if (i < 0) i = -i;
   if (i >= n) i = 2 * n - 2 - i;
@@ -126,14 +132,12 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const uint8_t* __restrict__ 
   if (cr.deltas & 0x8000) {
     const int cb = phase + ((int)cr.sxa - sxlo);
     const int ad = (cb >> 2) * 4, sh = cb & 3;
-    uint32_t sel[4];
-    int w0[4], w1[4];
+    uint32_t sel[4], wp[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const uint32_t d = (cr.deltas >> (3 * k)) & 7u;
       sel[k] = 0x0c000c00u | d | ((d + 1u) << 16);
-      w1[k] = cr.w1[k];
-      w0[k] = 2048 - w1[k];
+      wp[k] = (2048u - cr.w1[k]) | ((uint32_t)cr.w1[k] << 16);  // (left, right) weights
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -146,16 +150,16 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const uint8_t* __restrict__ 
         const uint32_t b0 = p1[0], b1 = p1[1], b2 = p1[2];
         const uint32_t alo = __builtin_amdgcn_alignbyte(a1, a0, sh), ahi = __builtin_amdgcn_alignbyte(a2, a1, sh);
         const uint32_t blo = __builtin_amdgcn_alignbyte(b1, b0, sh), bhi = __builtin_amdgcn_alignbyte(b2, b1, sh);
-        const int wy0 = ty.w0, wy1 = ty.w1;
+        const uint32_t wy0 = (uint32_t)(int)ty.w0, wy1 = (uint32_t)(int)ty.w1;  // 0..2048
         uint32_t out = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const uint32_t pa = __builtin_amdgcn_perm(ahi, alo, sel[k]);
-          const uint32_t pb = __builtin_amdgcn_perm(bhi, blo, sel[k]);
-          const int h0 = (int)(pa & 0xFFFF) * w0[k] + (int)(pa >> 16) * w1[k];
-          const int h1 = (int)(pb & 0xFFFF) * w0[k] + (int)(pb >> 16) * w1[k];
-          const int v = (((wy0 * (h0 >> 4)) >> 16) + ((wy1 * (h1 >> 4)) >> 16) + 2) >> 2;
-          out |= (uint32_t)(v & 0xFF) << (8 * k);
+          // horizontal: S[sx]*a0 + S[sx+1]*a1 (<= 255*2048); vertical: the 8-bit
+          // specialisation's ((b*(H>>4))>>16 + ... + 2) >> 2, all operands < 2^24
+          const uint32_t h0 = udot2(__builtin_amdgcn_perm(ahi, alo, sel[k]), wp[k], 0u);
+          const uint32_t h1 = udot2(__builtin_amdgcn_perm(bhi, blo, sel[k]), wp[k], 0u);
+          const uint32_t v = ((__umul24(wy0, h0 >> 4) >> 16) + (__umul24(wy1, h1 >> 4) >> 16) + 2u) >> 2;
+          out |= (v & 0xFFu) << (8 * k);
         }
         *(uint32_t*)(dcol + (size_t)py * pstride) = out;
       }
@@ -875,14 +879,32 @@ __global__ __launch_bounds__(256) void k_assemble(const Plan* __restrict__ plan,
 // column pass.  The source is the padded pyramid plane, whose own border is
 // the REFLECT_101 extension the blur needs.
 //
-// A lane owns 4 adjacent columns and walks down a band of rows.  Per input
-// row it reads 12 aligned bytes (the 10 it needs start at padded column
-// x0 + 16, a multiple of 4), forms the 4 horizontal sums in registers and
-// adds them, weighted, into 7 rolling column accumulators; the accumulator
-// that has seen all 7 rows is rounded and stored as one dword.  No LDS.
-// Block = 4 waves stacked vertically; a wave covers 256 columns x BLUR_BAND rows.
+// A lane owns 4 adjacent columns and walks down a band of rows, two rows per
+// step.  Per input row it reads 12 aligned bytes (the 10 it needs start at
+// padded column x0 + 16, a multiple of 4) and forms the 4 row sums with
+// v_alignbyte + two v_dot4_u32_u8 each.  Row sums of consecutive rows are kept
+// as 16-bit pairs in a rolling window of 4 pairs per column, from which two
+// output rows come out of eight v_dot2_u32_u16 (rounding constant fed in as
+// the accumulator).  No LDS.  Block = 4 waves stacked vertically; a wave covers
+// 256 columns x BLUR_BAND rows.
 // ---------------------------------------------------------------------------
 #define BLUR_BAND 64
+
+// the 4 horizontal sums of one input row (12 bytes in d0..d2)
+__device__ __forceinline__ void blur_hrow(const uint8_t* rowp, uint32_t (&h)[4]) {
+  const uint32_t* rp = (const uint32_t*)rowp;
+  const uint32_t d0 = rp[0], d1 = rp[1], d2 = rp[2];
+  const uint32_t KLO = 18u | (34u << 8) | (48u << 16) | (56u << 24);
+  const uint32_t KHI = 48u | (34u << 8) | (18u << 16);
+  h[0] = __builtin_amdgcn_udot4(d0, KLO, __builtin_amdgcn_udot4(d1, KHI, 0u, false), false);
+#pragma unroll
+  for (int c = 1; c < 4; ++c) {
+    const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, c);
+    const uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, c);
+    h[c] = __builtin_amdgcn_udot4(lo, KLO, __builtin_amdgcn_udot4(hi, KHI, 0u, false), false);
+  }
+}
+
 __global__ __launch_bounds__(256) void k_blur(const Plan* __restrict__ plan,
                                               const uint8_t* __restrict__ pyr,
                                               uint8_t* __restrict__ blur) {
@@ -898,48 +920,48 @@ __global__ __launch_bounds__(256) void k_blur(const Plan* __restrict__ plan,
   const int y0 = (tyi * 4 + wave) * BLUR_BAND;
   if (x0 >= L.w || y0 >= L.h) return;
   const int nout = min(BLUR_BAND, L.h - y0);
-  const int nin = nout + 6;
   // input row i of the band = level row y0 - 3 + i = padded row y0 + 16 + i
-  const uint8_t* src = pyr + L.pyr_off + (size_t)f * L.pyr_plane + (size_t)(y0 + 16) * L.pstride + (x0 + 16);
-  uint8_t* dst = blur + L.blur_off + (size_t)f * L.blur_plane + (size_t)y0 * L.bstride + x0;
   const int ps = L.pstride, bs = L.bstride;
-  uint32_t acc[7][4];
+  const uint8_t* src = pyr + L.pyr_off + (size_t)f * L.pyr_plane + (size_t)(y0 + 16) * ps + (x0 + 16);
+  uint8_t* dst = blur + L.blur_off + (size_t)f * L.blur_plane + (size_t)y0 * bs + x0;
+  // output rows (2t, 2t+1) need input rows 2t .. 2t+7 = row pairs t .. t+3
+  uint32_t Q[4][4];
 #pragma unroll
-  for (int j = 0; j < 7; ++j)
+  for (int m = 0; m < 3; ++m) {
+    uint32_t ha[4], hb[4];
+    blur_hrow(src + (size_t)(2 * m) * ps, ha);
+    blur_hrow(src + (size_t)(2 * m + 1) * ps, hb);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) acc[j][c] = 0;
-  const uint32_t K[7] = {18, 34, 48, 56, 48, 34, 18};
-  for (int i0 = 0; i0 < nin; i0 += 7) {
+    for (int c = 0; c < 4; ++c) Q[m][c] = ha[c] | (hb[c] << 16);
+  }
+  const uint32_t A0 = 18u | (34u << 16), A1 = 48u | (56u << 16), A2 = 48u | (34u << 16), A3 = 18u;
+  const uint32_t B0 = 18u << 16, B1 = 34u | (48u << 16), B2 = 56u | (48u << 16), B3 = 34u | (18u << 16);
+  for (int t0 = 0; 2 * t0 < nout; t0 += 4) {
 #pragma unroll
-    for (int s = 0; s < 7; ++s) {
-      const int i = i0 + s;
-      if (i < nin) {
-        const uint32_t* rp = (const uint32_t*)(src + (size_t)i * ps);
-        const uint32_t d0 = rp[0], d1 = rp[1], d2 = rp[2];
-        uint32_t b[10];
-        b[0] = d0 & 0xFF; b[1] = (d0 >> 8) & 0xFF; b[2] = (d0 >> 16) & 0xFF; b[3] = d0 >> 24;
-        b[4] = d1 & 0xFF; b[5] = (d1 >> 8) & 0xFF; b[6] = (d1 >> 16) & 0xFF; b[7] = d1 >> 24;
-        b[8] = d2 & 0xFF; b[9] = (d2 >> 8) & 0xFF;
-        uint32_t h[4];
+    for (int s = 0; s < 4; ++s) {
+      const int tt = t0 + s;
+      if (2 * tt < nout) {
+        uint32_t ha[4], hb[4];
+        blur_hrow(src + (size_t)(2 * tt + 6) * ps, ha);
+        blur_hrow(src + (size_t)(2 * tt + 7) * ps, hb);
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-          h[c] = 18u * (b[c] + b[c + 6]) + 34u * (b[c + 1] + b[c + 5]) + 48u * (b[c + 2] + b[c + 4]) + 56u * b[c + 3];
-        // input row i feeds outputs o = i - j (j = 0..6) with weight K[j]; slot of o is o mod 7
+        for (int c = 0; c < 4; ++c) Q[(s + 3) & 3][c] = ha[c] | (hb[c] << 16);
+        uint32_t ra[4], rb[4];
 #pragma unroll
-        for (int j = 0; j < 7; ++j) {
-          const int slot = (s - j + 7) % 7;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) acc[slot][c] += K[j] * h[c];
+        for (int c = 0; c < 4; ++c) {
+          const uint32_t p0 = Q[s & 3][c], p1 = Q[(s + 1) & 3][c], p2 = Q[(s + 2) & 3][c], p3 = Q[(s + 3) & 3][c];
+          ra[c] = udot2(p0, A0, udot2(p1, A1, udot2(p2, A2, udot2(p3, A3, 32768u))));
+          rb[c] = udot2(p0, B0, udot2(p1, B1, udot2(p2, B2, udot2(p3, B3, 32768u))));
         }
-        // output o = i - 6 is complete; its slot is (s + 1) mod 7
-        const int done = (s + 1) % 7;
-        if (i >= 6) {
-          const uint32_t o0 = (acc[done][0] + 32768u) >> 16, o1 = (acc[done][1] + 32768u) >> 16,
-                         o2 = (acc[done][2] + 32768u) >> 16, o3 = (acc[done][3] + 32768u) >> 16;
-          *(uint32_t*)(dst + (size_t)(i - 6) * bs) = o0 | (o1 << 8) | (o2 << 16) | (o3 << 24);
+        // result byte = bits 16..23 of each sum
+        const uint32_t oa = __builtin_amdgcn_perm(ra[1], ra[0], 0x0c0c0602u) |
+                            __builtin_amdgcn_perm(ra[3], ra[2], 0x06020c0cu);
+        *(uint32_t*)(dst + (size_t)(2 * tt) * bs) = oa;
+        if (2 * tt + 1 < nout) {
+          const uint32_t ob = __builtin_amdgcn_perm(rb[1], rb[0], 0x0c0c0602u) |
+                              __builtin_amdgcn_perm(rb[3], rb[2], 0x06020c0cu);
+          *(uint32_t*)(dst + (size_t)(2 * tt + 1) * bs) = ob;
         }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[done][c] = 0;
       }
     }
   }
@@ -1016,8 +1038,8 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Plan* __restrict_
     const uint8_t* rp = center + v * ps;
     const int a = au0 <= lim ? (int)rp[u0] : 0;
     const int b = au1 <= lim ? (int)rp[u1] : 0;   // u1 = 16 never passes (lim <= 15)
-    m10 += u0 * a + u1 * b;
-    m01 += v * (a + b);
+    m10 += __mul24(u0, a) + __mul24(u1, b);
+    m01 += __mul24(v, a + b);
   }
 #pragma unroll
   for (int d = 8; d >= 1; d >>= 1) {
