@@ -307,6 +307,7 @@ int orbx_extractor::ensurePlan(int W, int H) {
     const int pw = L.w + 2 * ORBX_EDGE, ph = L.prows;
     const int ncol = L.pstride / 4;
     std::vector<ColRec> cr(ncol);
+    std::vector<uint16_t> bc;
     for (int c = 0; c < ncol; ++c) {
       ColRec r;
       std::memset(&r, 0, sizeof(r));
@@ -325,6 +326,7 @@ int orbx_extractor::ensurePlan(int W, int H) {
       }
       if (ok) r.deltas |= 0x8000; else r.deltas = 0;
       cr[c] = r;
+      if (!ok && 4 * c < pw) bc.push_back((uint16_t)c);
     }
     const int nbx = (L.pstride + 255) / 256, nby = (ph + 15) / 16;
     std::vector<uint16_t> xb(2 * nbx), yb(2 * nby);
@@ -351,7 +353,10 @@ int orbx_extractor::ensurePlan(int W, int H) {
     L.rs_ls = round_up(spanx + 3 + 12, 4);   // phase (<=3) + span + 3-dword window overrun
     L.rs_rows = spany;
     resizeLds = std::max(resizeLds, (size_t)L.rs_ls * L.rs_rows);
-    void *dx = nullptr, *dy = nullptr, *dc = nullptr, *dxb = nullptr, *dyb = nullptr;
+    void *dx = nullptr, *dy = nullptr, *dc = nullptr, *dxb = nullptr, *dyb = nullptr, *dbc = nullptr;
+    HIP_TRY(hipMalloc(&dbc, bc.size() * 2 + 2)); d_taps.push_back(dbc);
+    HIP_TRY(hipMemcpy(dbc, bc.data(), bc.size() * 2, hipMemcpyHostToDevice));
+    L.bcols = (const uint16_t*)dbc; L.n_bcols = (int)bc.size();
     HIP_TRY(hipMalloc(&dx, tx.size() * sizeof(Tap))); d_taps.push_back(dx);
     HIP_TRY(hipMalloc(&dy, ty.size() * sizeof(Tap))); d_taps.push_back(dy);
     HIP_TRY(hipMalloc(&dc, cr.size() * sizeof(ColRec))); d_taps.push_back(dc);

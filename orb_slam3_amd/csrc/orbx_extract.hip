@@ -58,29 +58,72 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 }
 
 // ---------------------------------------------------------------------------
-// K1a: level 0 = input image + 19-pixel REFLECT_101 border
-// Thread = one aligned dword (4 pixels) of the padded plane.
+// K1a: level 0 = input image + 19-pixel REFLECT_101 border.
+// A lane produces 16 padded pixels (one 16-byte store) of 2 rows.  Interior
+// groups read 20 source bytes per row with dword-aligned wide loads and
+// re-base them with v_alignbyte; groups that touch the border go per byte.
 // ---------------------------------------------------------------------------
+struct __attribute__((packed, aligned(4))) U4A4 { uint32_t x, y, z, w; };
+#define L0_ROWS 4  // rows per lane
+
 __global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t* __restrict__ img, int W, int H,
                                                     int istride, size_t iframe,
                                                     uint8_t* __restrict__ dst, int pstride,
-                                                    int prows, size_t dplane) {
-  const int c = blockIdx.x * 64 + threadIdx.x;
-  const int py = blockIdx.y * 4 + threadIdx.y;
+                                                    int prows, size_t dplane, int nbx) {
   const int f = blockIdx.z;
-  if (c * 4 >= pstride || py >= prows) return;
-  const int sy = reflect101(py - ORBX_EDGE, H);
-  const uint8_t* srow = img + (size_t)f * iframe + (size_t)sy * istride;
-  uint32_t out = 0;
+  const uint8_t* fimg = img + (size_t)f * iframe;
+  // 16-pixel groups [2, ghi] are interior: all 16 pixels and the slack bytes the aligned
+  // loads may touch lie inside the source row
+  const int ghi = (W - 1) / 16;
+  if ((int)blockIdx.x < nbx) {
+    const int g = blockIdx.x * 64 + threadIdx.x;
+    const int py0 = (blockIdx.y * 4 + threadIdx.y) * L0_ROWS;
+    if (g < 2 || g > ghi) return;
+    const int P = g * 16;
+    uint8_t* fdst = dst + (size_t)f * dplane + P;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int px = 4 * c + k;
-    if (px < W + 2 * ORBX_EDGE) {
-      const int sx = reflect101(px - ORBX_EDGE, W);
-      out |= (uint32_t)srow[sx] << (8 * k);
+    for (int r = 0; r < L0_ROWS; ++r) {
+      const int py = py0 + r;
+      if (py >= prows) break;
+      const int sy = reflect101(py - ORBX_EDGE, H);
+      const uintptr_t a = (uintptr_t)(fimg + (size_t)sy * istride + (P - ORBX_EDGE));
+      const int sh = (int)(a & 3);
+      const uint8_t* ap = (const uint8_t*)(a - sh);
+      const U4A4 v = *(const U4A4*)ap;
+      const uint32_t v4 = *(const uint32_t*)(ap + 16);
+      uint4 out;
+      out.x = __builtin_amdgcn_alignbyte(v.y, v.x, sh);
+      out.y = __builtin_amdgcn_alignbyte(v.z, v.y, sh);
+      out.z = __builtin_amdgcn_alignbyte(v.w, v.z, sh);
+      out.w = __builtin_amdgcn_alignbyte(v4, v.w, sh);
+      *(uint4*)(fdst + (size_t)py * pstride) = out;
+    }
+  } else {
+    // border block: one lane per (row, dword) of the left 8 and the right border dwords
+    const int cr0 = 4 * (ghi + 1);
+    const int nright = (W + 2 * ORBX_EDGE + 3) / 4 - cr0;
+    const int nb = 8 + nright;
+    const int rows = 4 * L0_ROWS;
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    const float rnb = 1.0f / (float)nb;
+    for (int t = tid; t < rows * nb; t += 256) {
+      const int r = (int)(((float)t + 0.5f) * rnb);
+      const int j = t - r * nb;
+      const int py = blockIdx.y * rows + r;
+      if (py >= prows) break;
+      const int c = j < 8 ? j : cr0 + (j - 8);
+      const uint8_t* srow = fimg + (size_t)reflect101(py - ORBX_EDGE, H) * istride;
+      uint32_t out = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int px = 4 * c + k;
+        const int sx = reflect101(min(px, W + 2 * ORBX_EDGE - 1) - ORBX_EDGE, W);
+        const uint32_t v = srow[sx];
+        out |= (px < W + 2 * ORBX_EDGE ? v : 0u) << (8 * k);
+      }
+      *(uint32_t*)(dst + (size_t)f * dplane + (size_t)py * pstride + 4 * c) = out;
     }
   }
-  *(uint32_t*)(dst + (size_t)f * dplane + (size_t)py * pstride + 4 * c) = out;
 }
 
 // ---------------------------------------------------------------------------
@@ -103,10 +146,39 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const uint8_t* __restrict__ 
                                                     const Tap* __restrict__ ytab,
                                                     const ColRec* __restrict__ colrec,
                                                     const uint16_t* __restrict__ xblk,
-                                                    const uint16_t* __restrict__ yblk, int LS) {
+                                                    const uint16_t* __restrict__ yblk, int LS,
+                                                    const uint16_t* __restrict__ bcols, int nbc, int nbx) {
   extern __shared__ __align__(16) uint8_t smem[];
   const int tid = threadIdx.y * 64 + threadIdx.x;
   const int f = blockIdx.z;
+  if ((int)blockIdx.x >= nbx) {
+    // border block: one lane per (row, border dword); taps straight from the tables,
+    // source bytes straight from the (cache-resident) source plane
+    const uint8_t* roi = src + (size_t)f * splane + (size_t)ORBX_EDGE * sstride + ORBX_EDGE;
+    const float rnb = 1.0f / (float)nbc;
+    for (int t = tid; t < 16 * nbc; t += 256) {
+      const int r = (int)(((float)t + 0.5f) * rnb);
+      const int py = blockIdx.y * 16 + r;
+      if (py >= prows) break;
+      const int c = bcols[t - r * nbc];
+      const Tap ty = ytab[py];
+      const uint8_t* r0 = roi + (size_t)ty.s0 * sstride;
+      const uint8_t* r1 = roi + (size_t)ty.s1 * sstride;
+      uint32_t out = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int px = 4 * c + k;
+        const Tap tx = xtab[min(px, pw - 1)];
+        const uint32_t h0 = __umul24(r0[tx.s0], (uint32_t)(int)tx.w0) + __umul24(r0[tx.s1], (uint32_t)(int)tx.w1);
+        const uint32_t h1 = __umul24(r1[tx.s0], (uint32_t)(int)tx.w0) + __umul24(r1[tx.s1], (uint32_t)(int)tx.w1);
+        const uint32_t v = ((__umul24((uint32_t)(int)ty.w0, h0 >> 4) >> 16) +
+                            (__umul24((uint32_t)(int)ty.w1, h1 >> 4) >> 16) + 2u) >> 2;
+        out |= (px < pw ? (v & 0xFFu) : 0u) << (8 * k);
+      }
+      *(uint32_t*)(dst + (size_t)f * dplane + (size_t)py * pstride + 4 * c) = out;
+    }
+    return;
+  }
   const int sxlo = xblk[2 * blockIdx.x], sxhi = xblk[2 * blockIdx.x + 1];
   const int sylo = yblk[2 * blockIdx.y], syhi = yblk[2 * blockIdx.y + 1];
   // source ROI starts 19 rows / 19 bytes into the (64-byte aligned) plane
@@ -114,21 +186,36 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const uint8_t* __restrict__ 
   const uint8_t* g0 = src + (size_t)f * splane + (size_t)(ORBX_EDGE + sylo) * sstride + (ORBX_EDGE + sxlo - phase);
   const int nd = (phase + (sxhi - sxlo + 1) + 3 + 8) >> 2;   // dwords per row incl. window overrun
   const int nr = syhi - sylo + 1;
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  const bool live = c * 4 < pstride;  // columns without a valid record belong to the border block
+  const ColRec cr = colrec[live ? c : 0];
+  const int py0 = blockIdx.y * 16 + threadIdx.y * 4;
+  Tap tys[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) tys[r] = ytab[min(py0 + r, prows - 1)];
   {
     const int total = nr * nd;
     const float rnd = 1.0f / (float)nd;
-    for (int i = tid; i < total; i += 256) {
-      const int r = (int)(((float)i + 0.5f) * rnd);
-      const int n = i - r * nd;
-      *(uint32_t*)(smem + r * LS + 4 * n) = *((const uint32_t*)(g0 + (size_t)r * sstride) + n);
+    for (int i0 = tid; i0 < total; i0 += 256 * 8) {
+      uint32_t v[8];
+      int off[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * 256;
+        const int ic = min(i, total - 1);
+        const int r = (int)(((float)ic + 0.5f) * rnd);
+        const int n = ic - r * nd;
+        off[u] = i < total ? r * LS + 4 * n : -1;
+        v[u] = *((const uint32_t*)(g0 + (size_t)r * sstride) + n);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (off[u] >= 0) *(uint32_t*)(smem + off[u]) = v[u];
     }
   }
   __syncthreads();
-  const int c = blockIdx.x * 64 + threadIdx.x;
-  if (c * 4 >= pstride) return;
-  const ColRec cr = colrec[c];
+  if (!live) return;
   uint8_t* dcol = dst + (size_t)f * dplane + 4 * c;
-  const int py0 = blockIdx.y * 16 + threadIdx.y * 4;
   if (cr.deltas & 0x8000) {
     const int cb = phase + ((int)cr.sxa - sxlo);
     const int ad = (cb >> 2) * 4, sh = cb & 3;
@@ -143,7 +230,7 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const uint8_t* __restrict__ 
     for (int r = 0; r < 4; ++r) {
       const int py = py0 + r;
       if (py < prows) {
-        const Tap ty = ytab[py];
+        const Tap ty = tys[r];
         const uint32_t* p0 = (const uint32_t*)(smem + ((int)ty.s0 - sylo) * LS + ad);
         const uint32_t* p1 = (const uint32_t*)(smem + ((int)ty.s1 - sylo) * LS + ad);
         const uint32_t a0 = p0[0], a1 = p0[1], a2 = p0[2];
@@ -160,28 +247,6 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const uint8_t* __restrict__ 
           const uint32_t h1 = udot2(__builtin_amdgcn_perm(bhi, blo, sel[k]), wp[k], 0u);
           const uint32_t v = ((__umul24(wy0, h0 >> 4) >> 16) + (__umul24(wy1, h1 >> 4) >> 16) + 2u) >> 2;
           out |= (v & 0xFFu) << (8 * k);
-        }
-        *(uint32_t*)(dcol + (size_t)py * pstride) = out;
-      }
-    }
-  } else {
-#pragma unroll 1
-    for (int r = 0; r < 4; ++r) {
-      const int py = py0 + r;
-      if (py < prows) {
-        const Tap ty = ytab[py];
-        const uint8_t* r0 = smem + ((int)ty.s0 - sylo) * LS + phase - sxlo;
-        const uint8_t* r1 = smem + ((int)ty.s1 - sylo) * LS + phase - sxlo;
-        uint32_t out = 0;
-        for (int k = 0; k < 4; ++k) {
-          const int px = 4 * c + k;
-          if (px < pw) {
-            const Tap tx = xtab[px];
-            const int h0 = (int)r0[tx.s0] * tx.w0 + (int)r0[tx.s1] * tx.w1;
-            const int h1 = (int)r1[tx.s0] * tx.w0 + (int)r1[tx.s1] * tx.w1;
-            const int v = ((((int)ty.w0 * (h0 >> 4)) >> 16) + (((int)ty.w1 * (h1 >> 4)) >> 16) + 2) >> 2;
-            out |= (uint32_t)(v & 0xFF) << (8 * k);
-          }
         }
         *(uint32_t*)(dcol + (size_t)py * pstride) = out;
       }
@@ -1088,17 +1153,20 @@ void launch_pyramid(const Plan& hp, const uint8_t* d_img, int istride, size_t if
   const dim3 blk(64, 4);
   {
     const LevelDesc& L = hp.lv[0];
-    dim3 grid((L.pstride / 4 + 63) / 64, (L.prows + 3) / 4, nframes);
+    const int nbx = (L.pstride / 16 + 63) / 64;
+    dim3 grid(nbx + 1, (L.prows + 4 * L0_ROWS - 1) / (4 * L0_ROWS), nframes);
     hipLaunchKernelGGL(k_pyr_level0, grid, blk, 0, s, d_img, hp.W, hp.H, istride, iframe,
-                       d_pyr + L.pyr_off, L.pstride, L.prows, L.pyr_plane);
+                       d_pyr + L.pyr_off, L.pstride, L.prows, L.pyr_plane, nbx);
   }
   for (int l = 1; l < hp.nlevels; ++l) {
     const LevelDesc& S = hp.lv[l - 1];
     const LevelDesc& L = hp.lv[l];
-    dim3 grid((L.pstride + 255) / 256, (L.prows + 15) / 16, nframes);
+    const int nbx = (L.pstride + 255) / 256;
+    dim3 grid(nbx + 1, (L.prows + 15) / 16, nframes);
     hipLaunchKernelGGL(k_pyr_resize, grid, blk, (size_t)L.rs_ls * L.rs_rows + 16, s, d_pyr + S.pyr_off,
                        S.pstride, S.pyr_plane, d_pyr + L.pyr_off, L.pstride, L.prows, L.pyr_plane,
-                       L.w + 2 * ORBX_EDGE, L.xtab, L.ytab, L.colrec, L.xblk, L.yblk, L.rs_ls);
+                       L.w + 2 * ORBX_EDGE, L.xtab, L.ytab, L.colrec, L.xblk, L.yblk, L.rs_ls, L.bcols,
+                       L.n_bcols, nbx);
   }
 }
 

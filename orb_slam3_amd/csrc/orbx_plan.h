@@ -62,6 +62,8 @@ struct LevelDesc {
   const ColRec* colrec;  // [pstride / 4]
   const uint16_t* xblk;  // per 256-column block: lowest / highest source x touched
   const uint16_t* yblk;  // per 16-row block: lowest / highest source y touched
+  const uint16_t* bcols; // dword columns that need the per-pixel tap path (borders)
+  int n_bcols;
   int rs_ls;             // LDS row stride (bytes) for this level's source windows
   int rs_rows;           // LDS rows
 };
