@@ -131,13 +131,10 @@ __global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t* __restrict__ 
 // The tap tables are indexed by padded destination coordinates, so border
 // pixels are produced by the same code as interior ones.
 //
-// A block produces a 256 x 16 tile of the padded destination plane.  The
-// source window the tile touches is staged in LDS with coalesced dword loads;
-// a lane then owns one destination dword column (4 pixels) over 4 rows.
-// Interior columns take the fast path: the 8 source bytes that hold all taps
-// of the 4 pixels are re-based with v_alignbyte and each pixel's tap pair is
-// picked with one v_perm_b32.  Columns in the reflected border or at the
-// clamped right edge use the per-pixel tap table.
+// A block produces a 256 x 16 tile of the padded destination plane; the columns
+// in the reflected border or at the clamped right edge are produced by one
+// extra block per tile row through the per-pixel tap table, so that no wave
+// mixes the two code paths.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pyr_resize(const uint8_t* __restrict__ src, int sstride,
                                                     size_t splane, uint8_t* __restrict__ dst,
@@ -145,10 +142,7 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const uint8_t* __restrict__ 
                                                     const Tap* __restrict__ xtab,
                                                     const Tap* __restrict__ ytab,
                                                     const ColRec* __restrict__ colrec,
-                                                    const uint16_t* __restrict__ xblk,
-                                                    const uint16_t* __restrict__ yblk, int LS,
                                                     const uint16_t* __restrict__ bcols, int nbc, int nbx) {
-  extern __shared__ __align__(16) uint8_t smem[];
   const int tid = threadIdx.y * 64 + threadIdx.x;
   const int f = blockIdx.z;
   if ((int)blockIdx.x >= nbx) {
@@ -179,77 +173,55 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const uint8_t* __restrict__ 
     }
     return;
   }
-  const int sxlo = xblk[2 * blockIdx.x], sxhi = xblk[2 * blockIdx.x + 1];
-  const int sylo = yblk[2 * blockIdx.y], syhi = yblk[2 * blockIdx.y + 1];
-  // source ROI starts 19 rows / 19 bytes into the (64-byte aligned) plane
-  const int phase = (ORBX_EDGE + sxlo) & 3;
-  const uint8_t* g0 = src + (size_t)f * splane + (size_t)(ORBX_EDGE + sylo) * sstride + (ORBX_EDGE + sxlo - phase);
-  const int nd = (phase + (sxhi - sxlo + 1) + 3 + 8) >> 2;   // dwords per row incl. window overrun
-  const int nr = syhi - sylo + 1;
+  // main blocks: one lane = one destination dword column (4 pixels) x 4 rows.  The 8
+  // source bytes that hold all taps of the 4 pixels are fetched per source row as three
+  // dword-aligned words straight from the source plane (neighbouring lanes overlap, so
+  // the vector cache serves most of it), re-based with v_alignbyte, and each pixel's
+  // tap pair is picked with one v_perm_b32.  All loads of a lane are independent.
   const int c = blockIdx.x * 64 + threadIdx.x;
-  const bool live = c * 4 < pstride;  // columns without a valid record belong to the border block
-  const ColRec cr = colrec[live ? c : 0];
+  if (c * 4 >= pstride) return;
+  const ColRec cr = colrec[c];
+  if (!(cr.deltas & 0x8000)) return;   // border column: done by the border block
   const int py0 = blockIdx.y * 16 + threadIdx.y * 4;
   Tap tys[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) tys[r] = ytab[min(py0 + r, prows - 1)];
-  {
-    const int total = nr * nd;
-    const float rnd = 1.0f / (float)nd;
-    for (int i0 = tid; i0 < total; i0 += 256 * 8) {
-      uint32_t v[8];
-      int off[8];
+  const int sh = (ORBX_EDGE + (int)cr.sxa) & 3;   // planes and rows are 64-byte aligned
+  const uint8_t* base = src + (size_t)f * splane + (size_t)ORBX_EDGE * sstride + (ORBX_EDGE + (int)cr.sxa - sh);
+  uint32_t ra[4][3], rb[4][3];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int i = i0 + u * 256;
-        const int ic = min(i, total - 1);
-        const int r = (int)(((float)ic + 0.5f) * rnd);
-        const int n = ic - r * nd;
-        off[u] = i < total ? r * LS + 4 * n : -1;
-        v[u] = *((const uint32_t*)(g0 + (size_t)r * sstride) + n);
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (off[u] >= 0) *(uint32_t*)(smem + off[u]) = v[u];
-    }
+  for (int r = 0; r < 4; ++r) {
+    const uint32_t* p0 = (const uint32_t*)(base + (size_t)tys[r].s0 * sstride);
+    const uint32_t* p1 = (const uint32_t*)(base + (size_t)tys[r].s1 * sstride);
+    ra[r][0] = p0[0]; ra[r][1] = p0[1]; ra[r][2] = p0[2];
+    rb[r][0] = p1[0]; rb[r][1] = p1[1]; rb[r][2] = p1[2];
   }
-  __syncthreads();
-  if (!live) return;
+  uint32_t sel[4], wp[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t d = (cr.deltas >> (3 * k)) & 7u;
+    sel[k] = 0x0c000c00u | d | ((d + 1u) << 16);
+    wp[k] = (2048u - cr.w1[k]) | ((uint32_t)cr.w1[k] << 16);  // (left, right) weights
+  }
   uint8_t* dcol = dst + (size_t)f * dplane + 4 * c;
-  if (cr.deltas & 0x8000) {
-    const int cb = phase + ((int)cr.sxa - sxlo);
-    const int ad = (cb >> 2) * 4, sh = cb & 3;
-    uint32_t sel[4], wp[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const uint32_t d = (cr.deltas >> (3 * k)) & 7u;
-      sel[k] = 0x0c000c00u | d | ((d + 1u) << 16);
-      wp[k] = (2048u - cr.w1[k]) | ((uint32_t)cr.w1[k] << 16);  // (left, right) weights
-    }
+  for (int r = 0; r < 4; ++r) {
+    const int py = py0 + r;
+    if (py < prows) {
+      const uint32_t alo = __builtin_amdgcn_alignbyte(ra[r][1], ra[r][0], sh), ahi = __builtin_amdgcn_alignbyte(ra[r][2], ra[r][1], sh);
+      const uint32_t blo = __builtin_amdgcn_alignbyte(rb[r][1], rb[r][0], sh), bhi = __builtin_amdgcn_alignbyte(rb[r][2], rb[r][1], sh);
+      const uint32_t wy0 = (uint32_t)(int)tys[r].w0, wy1 = (uint32_t)(int)tys[r].w1;  // 0..2048
+      uint32_t out = 0;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int py = py0 + r;
-      if (py < prows) {
-        const Tap ty = tys[r];
-        const uint32_t* p0 = (const uint32_t*)(smem + ((int)ty.s0 - sylo) * LS + ad);
-        const uint32_t* p1 = (const uint32_t*)(smem + ((int)ty.s1 - sylo) * LS + ad);
-        const uint32_t a0 = p0[0], a1 = p0[1], a2 = p0[2];
-        const uint32_t b0 = p1[0], b1 = p1[1], b2 = p1[2];
-        const uint32_t alo = __builtin_amdgcn_alignbyte(a1, a0, sh), ahi = __builtin_amdgcn_alignbyte(a2, a1, sh);
-        const uint32_t blo = __builtin_amdgcn_alignbyte(b1, b0, sh), bhi = __builtin_amdgcn_alignbyte(b2, b1, sh);
-        const uint32_t wy0 = (uint32_t)(int)ty.w0, wy1 = (uint32_t)(int)ty.w1;  // 0..2048
-        uint32_t out = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          // horizontal: S[sx]*a0 + S[sx+1]*a1 (<= 255*2048); vertical: the 8-bit
-          // specialisation's ((b*(H>>4))>>16 + ... + 2) >> 2, all operands < 2^24
-          const uint32_t h0 = udot2(__builtin_amdgcn_perm(ahi, alo, sel[k]), wp[k], 0u);
-          const uint32_t h1 = udot2(__builtin_amdgcn_perm(bhi, blo, sel[k]), wp[k], 0u);
-          const uint32_t v = ((__umul24(wy0, h0 >> 4) >> 16) + (__umul24(wy1, h1 >> 4) >> 16) + 2u) >> 2;
-          out |= (v & 0xFFu) << (8 * k);
-        }
-        *(uint32_t*)(dcol + (size_t)py * pstride) = out;
+      for (int k = 0; k < 4; ++k) {
+        // horizontal: S[sx]*a0 + S[sx+1]*a1 (<= 255*2048); vertical: the 8-bit
+        // specialisation's ((b*(H>>4))>>16 + ... + 2) >> 2, all operands < 2^24
+        const uint32_t h0 = udot2(__builtin_amdgcn_perm(ahi, alo, sel[k]), wp[k], 0u);
+        const uint32_t h1 = udot2(__builtin_amdgcn_perm(bhi, blo, sel[k]), wp[k], 0u);
+        const uint32_t v = ((__umul24(wy0, h0 >> 4) >> 16) + (__umul24(wy1, h1 >> 4) >> 16) + 2u) >> 2;
+        out |= (v & 0xFFu) << (8 * k);
       }
+      *(uint32_t*)(dcol + (size_t)py * pstride) = out;
     }
   }
 }
@@ -1163,9 +1135,9 @@ void launch_pyramid(const Plan& hp, const uint8_t* d_img, int istride, size_t if
     const LevelDesc& L = hp.lv[l];
     const int nbx = (L.pstride + 255) / 256;
     dim3 grid(nbx + 1, (L.prows + 15) / 16, nframes);
-    hipLaunchKernelGGL(k_pyr_resize, grid, blk, (size_t)L.rs_ls * L.rs_rows + 16, s, d_pyr + S.pyr_off,
+    hipLaunchKernelGGL(k_pyr_resize, grid, blk, 0, s, d_pyr + S.pyr_off,
                        S.pstride, S.pyr_plane, d_pyr + L.pyr_off, L.pstride, L.prows, L.pyr_plane,
-                       L.w + 2 * ORBX_EDGE, L.xtab, L.ytab, L.colrec, L.xblk, L.yblk, L.rs_ls, L.bcols,
+                       L.w + 2 * ORBX_EDGE, L.xtab, L.ytab, L.colrec, L.bcols,
                        L.n_bcols, nbx);
   }
 }
