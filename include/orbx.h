@@ -130,6 +130,12 @@ int orbx_debug_level_selected(orbx_extractor* ex, int frame, int level, int32_t*
 /* Blurred level image (width*height bytes, contiguous). */
 int orbx_debug_level_blurred(orbx_extractor* ex, int frame, int level, uint8_t* dst);
 
+/* Sorts n 64-bit records (high word = comparison key, low word = payload) on the device
+ * with the quadtree kernel's sort, which must reproduce the permutation of
+ * std::sort(..., compareNodes) (extractor.cc:528-541, 673-674) including the order of
+ * records with equal keys.  n <= 3000.  Test hook. */
+int orbx_debug_sort_records(int device_id, uint64_t* records, int n);
+
 /* ---- timing --------------------------------------------------------------- */
 #define ORBX_STAGE_PYRAMID 0
 #define ORBX_STAGE_FAST 1

@@ -70,6 +70,7 @@ SIGNATURES = {
     "orbx_debug_level_candidates": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, _i32p]),
     "orbx_debug_level_selected": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, _i32p]),
     "orbx_debug_level_blurred": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "orbx_debug_sort_records": (C.c_int, [C.c_int, _P, C.c_int]),
     "orbx_set_profiling": (C.c_int, [_P, C.c_int]),
     "orbx_stage_times": (C.c_int, [_P, _f32p, C.c_int]),
     "orbx_hamming": (C.c_int, [_P, _P]),

@@ -16,21 +16,22 @@
 
 namespace orbx {
 void launch_pyramid(const Plan& hp, const uint8_t* d_img, int istride, size_t iframe, uint8_t* d_pyr,
-                    int nframes, hipStream_t s);
+                    int f0, int nframes, hipStream_t s);
 void launch_fast(const Plan& hp, const Plan* dp, const uint8_t* d_pyr, uint32_t* d_cand,
-                 int* d_cellCount, int nframes, hipStream_t s);
+                 int* d_cellCount, int f0, int nframes, hipStream_t s);
 void launch_octree(const Plan& hp, const Plan* dp, const uint32_t* d_cand, const int* d_cellCount,
                    uint32_t* d_flatA, uint32_t* d_flatB, uint32_t* d_sel, int* d_selCount,
-                   int nframes, hipStream_t s);
+                   int f0, int nframes, hipStream_t s);
 void launch_assemble(const Plan& hp, const Plan* dp, const uint32_t* d_sel, const int* d_selCount,
                      int lap0, int lap1, float* d_kps, WorkItem* d_work, int* d_n, int* d_mono,
-                     int nframes, hipStream_t s);
-void launch_blur(const Plan& hp, const Plan* dp, const uint8_t* d_pyr, uint8_t* d_blur, int nframes,
-                 hipStream_t s);
+                     int f0, int nframes, hipStream_t s);
+void launch_blur(const Plan& hp, const Plan* dp, const uint8_t* d_pyr, uint8_t* d_blur, int f0,
+                 int nframes, hipStream_t s);
 void launch_describe(const Plan& hp, const Plan* dp, const uint8_t* d_pyr, const uint8_t* d_blur,
                      const WorkItem* d_work, const int* d_n, float* d_kps, uint8_t* d_desc,
-                     int nframes, hipStream_t s);
+                     int f0, int nframes, hipStream_t s);
 int octree_set_lds_limit(const Plan& hp);
+int launch_debug_sort(uint64_t* d_data, int n, hipStream_t s);
 }  // namespace orbx
 
 using orbx::LevelDesc;
@@ -78,6 +79,10 @@ struct orbx_extractor {
 
   int device = 0;
   hipStream_t stream = nullptr;
+  // side stream(s): independent stages run beside the latency-bound quadtree
+  static const int kLanes = 1;
+  hipStream_t lane[kLanes] = {};
+  hipEvent_t evFork = nullptr, evJoin[kLanes] = {};
   hipError_t last_hip_error = hipSuccess;
 
   // plan for the current image size
@@ -290,6 +295,12 @@ int orbx_extractor::ensurePlan(int W, int H) {
   hp.fast_words = (cwMax * chMax + 31) / 32;
   hp.oct_nodes_cap = nodesCap;
   hp.oct_cells_max = cellsMax;
+  {
+    // LDS key buffers of k_octree: what fits beside the node arrays in ~48 KB per wave
+    const long fixed = (long)nodesCap * 86 + (long)(cellsMax + 1) * 4 + 64;
+    const long keys = (32 * 1024 - fixed) / 8;
+    hp.oct_keys_lds = keys < 256 ? 0 : (int)std::min(keys, 8192L);
+  }
   maxKeypoints = selOff;
   pyr_bytes = pyrOff;
 
@@ -398,19 +409,36 @@ int orbx_extractor::run(const uint8_t* d_images, int istride, size_t iframe, int
                         int lap1) {
   hipStream_t s = stream;
   const bool prof = profiling;
-  if (prof) HIP_TRY(hipEventRecord(ev[0], s));
-  orbx::launch_pyramid(hp, d_images, istride, iframe, d_pyr, nframes, s);
-  if (prof) HIP_TRY(hipEventRecord(ev[1], s));
-  orbx::launch_fast(hp, dp, d_pyr, d_cand, d_cellCount, nframes, s);
-  if (prof) HIP_TRY(hipEventRecord(ev[2], s));
-  orbx::launch_octree(hp, dp, d_cand, d_cellCount, d_flatA, d_flatB, d_sel, d_selCount, nframes, s);
-  if (prof) HIP_TRY(hipEventRecord(ev[3], s));
-  orbx::launch_assemble(hp, dp, d_sel, d_selCount, lap0, lap1, d_kps, d_work, d_n, d_mono, nframes, s);
-  if (prof) HIP_TRY(hipEventRecord(ev[4], s));
-  orbx::launch_blur(hp, dp, d_pyr, d_blur, nframes, s);
-  if (prof) HIP_TRY(hipEventRecord(ev[5], s));
-  orbx::launch_describe(hp, dp, d_pyr, d_blur, d_work, d_n, d_kps, d_desc, nframes, s);
-  if (prof) HIP_TRY(hipEventRecord(ev[6], s));
+  if (prof) {
+    // timing mode: one stream, stages back to back, HIP events around each stage
+    HIP_TRY(hipEventRecord(ev[0], s));
+    orbx::launch_pyramid(hp, d_images, istride, iframe, d_pyr, 0, nframes, s);
+    HIP_TRY(hipEventRecord(ev[1], s));
+    orbx::launch_fast(hp, dp, d_pyr, d_cand, d_cellCount, 0, nframes, s);
+    HIP_TRY(hipEventRecord(ev[2], s));
+    orbx::launch_octree(hp, dp, d_cand, d_cellCount, d_flatA, d_flatB, d_sel, d_selCount, 0, nframes, s);
+    HIP_TRY(hipEventRecord(ev[3], s));
+    orbx::launch_assemble(hp, dp, d_sel, d_selCount, lap0, lap1, d_kps, d_work, d_n, d_mono, 0, nframes, s);
+    HIP_TRY(hipEventRecord(ev[4], s));
+    orbx::launch_blur(hp, dp, d_pyr, d_blur, 0, nframes, s);
+    HIP_TRY(hipEventRecord(ev[5], s));
+    orbx::launch_describe(hp, dp, d_pyr, d_blur, d_work, d_n, d_kps, d_desc, 0, nframes, s);
+    HIP_TRY(hipEventRecord(ev[6], s));
+  } else {
+    // The quadtree runs one wave per (frame, level) and leaves most of the chip idle;
+    // the blur only needs the pyramid, so it runs beside it on a second stream.
+    hipStream_t q = lane[0];
+    orbx::launch_pyramid(hp, d_images, istride, iframe, d_pyr, 0, nframes, s);
+    orbx::launch_fast(hp, dp, d_pyr, d_cand, d_cellCount, 0, nframes, s);
+    HIP_TRY(hipEventRecord(evFork, s));
+    HIP_TRY(hipStreamWaitEvent(q, evFork, 0));
+    orbx::launch_blur(hp, dp, d_pyr, d_blur, 0, nframes, q);
+    HIP_TRY(hipEventRecord(evJoin[0], q));
+    orbx::launch_octree(hp, dp, d_cand, d_cellCount, d_flatA, d_flatB, d_sel, d_selCount, 0, nframes, s);
+    orbx::launch_assemble(hp, dp, d_sel, d_selCount, lap0, lap1, d_kps, d_work, d_n, d_mono, 0, nframes, s);
+    HIP_TRY(hipStreamWaitEvent(s, evJoin[0], 0));
+    orbx::launch_describe(hp, dp, d_pyr, d_blur, d_work, d_n, d_kps, d_desc, 0, nframes, s);
+  }
   evValid = prof;
   HIP_TRY(hipGetLastError());
   lastFrames = nframes;
@@ -456,7 +484,12 @@ int orbx_create(const orbx_params* p, orbx_extractor** out) {
     return ORBX_ERR_NO_DEVICE;
   }
   for (int i = 0; i <= ORBX_NUM_STAGES; ++i)
-    if (hipEventCreate(&ex->ev[i]) != hipSuccess) { delete ex; return ORBX_ERR_NO_DEVICE; }
+    if (hipEventCreate(&ex->ev[i]) != hipSuccess) { orbx_destroy(ex); return ORBX_ERR_NO_DEVICE; }
+  bool ok = hipEventCreateWithFlags(&ex->evFork, hipEventDisableTiming) == hipSuccess;
+  for (int k = 0; k < orbx_extractor::kLanes && ok; ++k)
+    ok = hipStreamCreateWithFlags(&ex->lane[k], hipStreamNonBlocking) == hipSuccess &&
+         hipEventCreateWithFlags(&ex->evJoin[k], hipEventDisableTiming) == hipSuccess;
+  if (!ok) { orbx_destroy(ex); return ORBX_ERR_NO_DEVICE; }
   *out = ex;
   return ORBX_OK;
 }
@@ -466,6 +499,11 @@ void orbx_destroy(orbx_extractor* ex) {
   (void)hipSetDevice(ex->device);
   ex->freePlan();
   for (int i = 0; i <= ORBX_NUM_STAGES; ++i) if (ex->ev[i]) (void)hipEventDestroy(ex->ev[i]);
+  for (int k = 0; k < orbx_extractor::kLanes; ++k) {
+    if (ex->lane[k]) { (void)hipStreamSynchronize(ex->lane[k]); (void)hipStreamDestroy(ex->lane[k]); }
+    if (ex->evJoin[k]) (void)hipEventDestroy(ex->evJoin[k]);
+  }
+  if (ex->evFork) (void)hipEventDestroy(ex->evFork);
   if (ex->stream) (void)hipStreamDestroy(ex->stream);
   delete ex;
 }
@@ -706,6 +744,21 @@ int orbx_debug_level_blurred(orbx_extractor* ex, int frame, int level, uint8_t* 
                     L.h, hipMemcpyDeviceToHost);
   if (e != hipSuccess) { ex->last_hip_error = e; return ORBX_ERR_HIP; }
   return ORBX_OK;
+}
+
+int orbx_debug_sort_records(int device_id, uint64_t* records, int n) {
+  if (!records || n < 0 || n > 3000) return ORBX_ERR_BAD_ARG;
+  if (n == 0) return ORBX_OK;
+  if (hipSetDevice(device_id) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  uint64_t* d = nullptr;
+  if (hipMalloc((void**)&d, (size_t)n * 8) != hipSuccess) return ORBX_ERR_HIP;
+  hipError_t e = hipMemcpy(d, records, (size_t)n * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess && orbx::launch_debug_sort(d, n, nullptr) != 0) e = hipErrorInvalidValue;
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(records, d, (size_t)n * 8, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  return e == hipSuccess ? ORBX_OK : ORBX_ERR_HIP;
 }
 
 int orbx_set_profiling(orbx_extractor* ex, int enabled) {

@@ -69,8 +69,8 @@ struct __attribute__((packed, aligned(4))) U4A4 { uint32_t x, y, z, w; };
 __global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t* __restrict__ img, int W, int H,
                                                     int istride, size_t iframe,
                                                     uint8_t* __restrict__ dst, int pstride,
-                                                    int prows, size_t dplane, int nbx) {
-  const int f = blockIdx.z;
+                                                    int prows, size_t dplane, int nbx, int f0) {
+  const int f = blockIdx.z + f0;
   const uint8_t* fimg = img + (size_t)f * iframe;
   // 16-pixel groups [2, ghi] are interior: all 16 pixels and the slack bytes the aligned
   // loads may touch lie inside the source row
@@ -142,9 +142,10 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const uint8_t* __restrict__ 
                                                     const Tap* __restrict__ xtab,
                                                     const Tap* __restrict__ ytab,
                                                     const ColRec* __restrict__ colrec,
-                                                    const uint16_t* __restrict__ bcols, int nbc, int nbx) {
+                                                    const uint16_t* __restrict__ bcols, int nbc, int nbx,
+                                                    int f0) {
   const int tid = threadIdx.y * 64 + threadIdx.x;
-  const int f = blockIdx.z;
+  const int f = blockIdx.z + f0;
   if ((int)blockIdx.x >= nbx) {
     // border block: one lane per (row, border dword); taps straight from the tables,
     // source bytes straight from the (cache-resident) source plane
@@ -356,10 +357,10 @@ template <int TS>
 __global__ __launch_bounds__(64) void k_fast_cells(const Plan* __restrict__ plan,
                                                    const uint8_t* __restrict__ pyr,
                                                    uint32_t* __restrict__ cand,
-                                                   int* __restrict__ cellCount) {
+                                                   int* __restrict__ cellCount, int f0) {
   extern __shared__ __align__(16) uint8_t smem[];
   const int lane = threadIdx.x;
-  const int f = blockIdx.y;
+  const int f = blockIdx.y + f0;
   const int cellg = blockIdx.x;
   int l = 0;
   while (l + 1 < plan->nlevels && cellg >= plan->lv[l + 1].cell_first) ++l;
@@ -510,12 +511,27 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Plan* __restrict__ plan
 // Keys are 32-bit: x | y << 12 | score << 24 with x, y relative to (16,16).
 // The node list is an array kept in list order; every node owns a contiguous
 // segment of one of two key buffers and a split writes the four children into
-// the same range of the other buffer (stable 4-way partition by ballots), so
-// key order inside a node is the parent's order, as in DivideNode.
+// the same range of the other buffer as a stable 4-way partition, so key
+// order inside a node is the parent's order, as in DivideNode.
 // A pass of the reference prepends children as they are created and erases
 // the parents, so the list after a pass is: the children in reverse creation
 // order, followed by the surviving old nodes in their old order.
+//
+// A pass is executed in three data-parallel steps over the nodes to split,
+// taken in the reference's processing order (list order in the whole-level
+// passes, sorted order from the back in the final rounds):
+//   count   - per node, keys per quadrant;
+//   place   - exclusive scan of the non-empty child counts gives every child
+//             its creation index; in the final rounds the running node total
+//             also gives the node at which the reference stops (:715-716);
+//   scatter - partition the keys and write the child records.
+// Nodes with at most OCT_SMALL keys are handled one node per lane (most nodes
+// in the later passes hold a handful of keys); larger ones by the whole wave
+// with ballots.  The key buffers live in LDS when the level's candidates fit,
+// else in the worst-case-sized global buffers.
 // ---------------------------------------------------------------------------
+#define OCT_SMALL 32
+
 struct QNode {
   short ulx, uly, brx, bry;
   int start;
@@ -525,98 +541,197 @@ struct QNode {
 __device__ __forceinline__ int qcount(const QNode& n) { return n.cnt & 0x7fffffff; }
 
 struct OctState {
-  QNode* newch;
-  int nch;
-  int nToExpand;
+  QNode* cur;        // node list, list order
+  QNode* nxt;
+  QNode* newch;      // children of the current pass, creation order
+  unsigned short* ord;   // list positions of the nodes to split, processing order
+  int4* cnt4;        // per ord entry: keys per quadrant
+  int* cbase;        // per ord entry: creation index of its first child
   uint32_t* bufA;
   uint32_t* bufB;
 };
 
-// Split one node (wave-cooperative).  Appends the non-empty children to
-// st.newch in n1..n4 order; returns the number of non-empty children.
-__device__ int split_node(const QNode nd, OctState& st) {
+__device__ __forceinline__ int quadrant_of(uint32_t key, int mx, int my) {
+  return ((int)(key & 0xFFF) >= mx ? 1 : 0) + ((int)((key >> 12) & 0xFFF) >= my ? 2 : 0);
+}
+
+// count step for ord[0..m)
+__device__ void oct_count(const OctState& st, int m) {
   const int lane = lane_id();
-  const int cnt = qcount(nd);
-  const int buf = (int)((unsigned)nd.cnt >> 31);
-  const uint32_t* src = (buf ? st.bufB : st.bufA) + nd.start;
-  uint32_t* dst = (buf ? st.bufA : st.bufB) + nd.start;
-  const int mx = nd.ulx + ((nd.brx - nd.ulx + 1) >> 1);  // ceil(width / 2)
-  const int my = nd.uly + ((nd.bry - nd.uly + 1) >> 1);
-  int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-  if (cnt <= 64) {
-    const bool valid = lane < cnt;
-    const uint32_t key = valid ? src[lane] : 0u;
-    const int x = key & 0xFFF, y = (key >> 12) & 0xFFF;
-    const int q = (x >= mx ? 1 : 0) + (y >= my ? 2 : 0);
-    const unsigned long long m0 = __ballot(valid && q == 0), m1 = __ballot(valid && q == 1),
-                             m2 = __ballot(valid && q == 2), m3 = __ballot(valid && q == 3);
-    c0 = __popcll(m0); c1 = __popcll(m1); c2 = __popcll(m2); c3 = __popcll(m3);
-    if (valid) {
-      int pos;
-      if (q == 0) pos = mbcnt64(m0);
-      else if (q == 1) pos = c0 + mbcnt64(m1);
-      else if (q == 2) pos = c0 + c1 + mbcnt64(m2);
-      else pos = c0 + c1 + c2 + mbcnt64(m3);
-      dst[pos] = key;
-    }
-  } else {
-    for (int base = 0; base < cnt; base += 64) {
-      const int i = base + lane;
-      const bool valid = i < cnt;
-      const uint32_t key = valid ? src[i] : 0u;
-      const int x = key & 0xFFF, y = (key >> 12) & 0xFFF;
-      const int q = (x >= mx ? 1 : 0) + (y >= my ? 2 : 0);
-      c0 += __popcll(__ballot(valid && q == 0));
-      c1 += __popcll(__ballot(valid && q == 1));
-      c2 += __popcll(__ballot(valid && q == 2));
-      c3 += __popcll(__ballot(valid && q == 3));
-    }
-    int r0 = 0, r1 = c0, r2 = c0 + c1, r3 = c0 + c1 + c2;
-    for (int base = 0; base < cnt; base += 64) {
-      const int i = base + lane;
-      const bool valid = i < cnt;
-      const uint32_t key = valid ? src[i] : 0u;
-      const int x = key & 0xFFF, y = (key >> 12) & 0xFFF;
-      const int q = (x >= mx ? 1 : 0) + (y >= my ? 2 : 0);
-      const unsigned long long m0 = __ballot(valid && q == 0), m1 = __ballot(valid && q == 1),
-                               m2 = __ballot(valid && q == 2), m3 = __ballot(valid && q == 3);
-      if (valid) {
-        int pos;
-        if (q == 0) pos = r0 + mbcnt64(m0);
-        else if (q == 1) pos = r1 + mbcnt64(m1);
-        else if (q == 2) pos = r2 + mbcnt64(m2);
-        else pos = r3 + mbcnt64(m3);
-        dst[pos] = key;
+  for (int base = 0; base < m; base += 64) {
+    const int t = base + lane;
+    QNode nd;
+    nd.cnt = 0;
+    if (t < m) nd = st.cur[st.ord[t]];
+    const int cnt = qcount(nd);
+    const bool big = cnt > OCT_SMALL;
+    if (t < m && !big) {
+      const uint32_t* src = (((unsigned)nd.cnt >> 31) ? st.bufB : st.bufA) + nd.start;
+      const int mx = nd.ulx + ((nd.brx - nd.ulx + 1) >> 1), my = nd.uly + ((nd.bry - nd.uly + 1) >> 1);
+      int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+      for (int k = 0; k < cnt; ++k) {
+        const int q = quadrant_of(src[k], mx, my);
+        c0 += q == 0; c1 += q == 1; c2 += q == 2; c3 += q == 3;
       }
-      r0 += __popcll(m0); r1 += __popcll(m1); r2 += __popcll(m2); r3 += __popcll(m3);
+      st.cnt4[t] = make_int4(c0, c1, c2, c3);
+    }
+    unsigned long long bigmask = __ballot(big);
+    while (bigmask) {
+      const int bl = __ffsll((long long)bigmask) - 1;
+      bigmask &= bigmask - 1;
+      const QNode bn = st.cur[st.ord[base + bl]];
+      const int bc = qcount(bn);
+      const uint32_t* src = (((unsigned)bn.cnt >> 31) ? st.bufB : st.bufA) + bn.start;
+      const int mx = bn.ulx + ((bn.brx - bn.ulx + 1) >> 1), my = bn.uly + ((bn.bry - bn.uly + 1) >> 1);
+      int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+      for (int kb = 0; kb < bc; kb += 64) {
+        const int i = kb + lane;
+        const bool valid = i < bc;
+        const int q = valid ? quadrant_of(src[i], mx, my) : -1;
+        c0 += __popcll(__ballot(q == 0));
+        c1 += __popcll(__ballot(q == 1));
+        c2 += __popcll(__ballot(q == 2));
+        c3 += __popcll(__ballot(q == 3));
+      }
+      if (lane == 0) st.cnt4[base + bl] = make_int4(c0, c1, c2, c3);
     }
   }
-  // children records (wave-uniform values; lane 0 stores)
-  const int nb = (buf ^ 1) << 31;
-  int made = 0;
+}
+
+// place step: creation index of every node's first child; returns the number of nodes
+// actually split (all of them, or up to the one that lifts the node total to N when
+// stopAtN), the number of children created and how many of those can be split again.
+__device__ int oct_place(const OctState& st, int m, int n0, int N, bool stopAtN, int* nchOut,
+                         int* nExpOut) {
+  const int lane = lane_id();
+  int childRun = 0, nodeRun = n0, mEff = m;
+  bool stopped = false;
+  for (int base = 0; base < m && !stopped; base += 64) {
+    const int t = base + lane;
+    int mch = 0;
+    if (t < m) {
+      const int4 c = st.cnt4[t];
+      mch = (c.x > 0) + (c.y > 0) + (c.z > 0) + (c.w > 0);
+    }
+    const int inc = wave_incl_scan(mch);
+    if (t < m) st.cbase[t] = childRun + inc - mch;
+    // node total after splitting entries 0..t: + children - 1 per split node
+    const int nodesAfter = nodeRun + inc - (lane + 1);
+    if (stopAtN) {
+      const unsigned long long hit = __ballot(t < m && nodesAfter >= N);
+      if (hit) {
+        const int first = __ffsll((long long)hit) - 1;
+        mEff = base + first + 1;
+        childRun += __shfl(inc, first, 64);
+        stopped = true;
+        break;
+      }
+    }
+    const int last = min(63, m - 1 - base);
+    childRun += __shfl(inc, last, 64);
+    nodeRun += __shfl(inc, last, 64) - (last + 1);
+  }
+  // children that hold more than one key, among the nodes actually split
+  int nexp = 0;
+  for (int base = 0; base < mEff; base += 64) {
+    const int t = base + lane;
+    int e = 0;
+    if (t < mEff) {
+      const int4 c = st.cnt4[t];
+      e = (c.x > 1) + (c.y > 1) + (c.z > 1) + (c.w > 1);
+    }
+    nexp += wave_sum(e);
+  }
+  *nchOut = childRun;
+  *nExpOut = nexp;
+  return mEff;
+}
+
+__device__ __forceinline__ void oct_write_children(const OctState& st, const QNode& nd, int4 c, int cb,
+                                                   int mx, int my) {
+  const int nb = (int)(((unsigned)nd.cnt >> 31) ^ 1u) << 31;
+  const int cc[4] = {c.x, c.y, c.z, c.w};
   int start = nd.start;
-  const int cc[4] = {c0, c1, c2, c3};
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const int c = cc[q];
-    if (c > 0) {
-      if (lane == 0) {
-        QNode ch;
-        ch.ulx = (q & 1) ? (short)mx : nd.ulx;
-        ch.brx = (q & 1) ? nd.brx : (short)mx;
-        ch.uly = (q & 2) ? (short)my : nd.uly;
-        ch.bry = (q & 2) ? nd.bry : (short)my;
-        ch.start = start;
-        ch.cnt = c | nb;
-        st.newch[st.nch + made] = ch;
-      }
-      ++made;
-      if (c > 1) ++st.nToExpand;
+    if (cc[q] > 0) {
+      QNode ch;
+      ch.ulx = (q & 1) ? (short)mx : nd.ulx;
+      ch.brx = (q & 1) ? nd.brx : (short)mx;
+      ch.uly = (q & 2) ? (short)my : nd.uly;
+      ch.bry = (q & 2) ? nd.bry : (short)my;
+      ch.start = start;
+      ch.cnt = cc[q] | nb;
+      st.newch[cb++] = ch;
     }
-    start += c;
+    start += cc[q];
   }
-  st.nch += made;
-  return made;
+}
+
+// scatter step for ord[0..mEff)
+__device__ void oct_scatter(const OctState& st, int mEff) {
+  const int lane = lane_id();
+  for (int base = 0; base < mEff; base += 64) {
+    const int t = base + lane;
+    QNode nd;
+    nd.cnt = 0;
+    int p = 0;
+    if (t < mEff) { p = st.ord[t]; nd = st.cur[p]; }
+    const int cnt = qcount(nd);
+    const bool big = cnt > OCT_SMALL;
+    if (t < mEff && !big) {
+      const int buf = (int)((unsigned)nd.cnt >> 31);
+      const uint32_t* src = (buf ? st.bufB : st.bufA) + nd.start;
+      uint32_t* dst = (buf ? st.bufA : st.bufB) + nd.start;
+      const int mx = nd.ulx + ((nd.brx - nd.ulx + 1) >> 1), my = nd.uly + ((nd.bry - nd.uly + 1) >> 1);
+      const int4 c = st.cnt4[t];
+      int o0 = 0, o1 = c.x, o2 = c.x + c.y, o3 = c.x + c.y + c.z;
+      for (int k = 0; k < cnt; ++k) {
+        const uint32_t key = src[k];
+        const int q = quadrant_of(key, mx, my);
+        const int pos = q == 0 ? o0 : q == 1 ? o1 : q == 2 ? o2 : o3;
+        dst[pos] = key;
+        o0 += q == 0; o1 += q == 1; o2 += q == 2; o3 += q == 3;
+      }
+      oct_write_children(st, nd, c, st.cbase[t], mx, my);
+      st.cur[p].cnt = 0;
+    }
+    unsigned long long bigmask = __ballot(big);
+    while (bigmask) {
+      const int bl = __ffsll((long long)bigmask) - 1;
+      bigmask &= bigmask - 1;
+      const int bp = st.ord[base + bl];
+      const QNode bn = st.cur[bp];
+      const int bc = qcount(bn);
+      const int buf = (int)((unsigned)bn.cnt >> 31);
+      const uint32_t* src = (buf ? st.bufB : st.bufA) + bn.start;
+      uint32_t* dst = (buf ? st.bufA : st.bufB) + bn.start;
+      const int mx = bn.ulx + ((bn.brx - bn.ulx + 1) >> 1), my = bn.uly + ((bn.bry - bn.uly + 1) >> 1);
+      const int4 c = st.cnt4[base + bl];
+      int r0 = 0, r1 = c.x, r2 = c.x + c.y, r3 = c.x + c.y + c.z;
+      for (int kb = 0; kb < bc; kb += 64) {
+        const int i = kb + lane;
+        const bool valid = i < bc;
+        const uint32_t key = valid ? src[i] : 0u;
+        const int q = valid ? quadrant_of(key, mx, my) : -1;
+        const unsigned long long m0 = __ballot(q == 0), m1 = __ballot(q == 1), m2 = __ballot(q == 2),
+                                 m3 = __ballot(q == 3);
+        if (valid) {
+          int pos;
+          if (q == 0) pos = r0 + mbcnt64(m0);
+          else if (q == 1) pos = r1 + mbcnt64(m1);
+          else if (q == 2) pos = r2 + mbcnt64(m2);
+          else pos = r3 + mbcnt64(m3);
+          dst[pos] = key;
+        }
+        r0 += __popcll(m0); r1 += __popcll(m1); r2 += __popcll(m2); r3 += __popcll(m3);
+      }
+      if (lane == 0) {
+        oct_write_children(st, bn, c, st.cbase[base + bl], mx, my);
+        st.cur[bp].cnt = 0;
+      }
+    }
+  }
 }
 
 // new list = reverse(newch[0..nch)) ++ [old nodes with cnt != 0, old order]
@@ -654,29 +769,149 @@ __device__ int build_records(const QNode* newch, int nch, orbx_sort::elem_t* rec
   return nrec;
 }
 
+// std::sort(v, v + n) of the split records, wave-parallel.  libstdc++'s introsort is
+// replayed partition by partition (see stdsort_emul.h for the serial form): the result of
+// one unguarded Hoare partition follows from the segment's contents before it -
+// the k-th swap exchanges the k-th element from the left that is not less than the pivot
+// with the k-th from the right that is not greater, as long as the former lies left of
+// the latter - so stopper lists, swap count and cut come from ballots instead of a
+// serial scan.  The closing insertion sort is stable and never moves an element across
+// a cut, i.e. it is a stable sort inside each final segment.  A segment whose depth
+// budget is spent is heap-sorted serially like the original (rare).
+// Scratch: posA/posB (n entries), segflag (n + 1 bytes), tmp (n elements), stk (3*64 ints).
+__device__ void oct_sort(orbx_sort::elem_t* v, int n, unsigned short* posA, unsigned short* posB,
+                         unsigned char* segflag, orbx_sort::elem_t* tmp, int* stk) {
+  using orbx_sort::less;
+  const int lane = lane_id();
+  if (n <= 1) return;
+  for (int i = lane; i <= n; i += 64) segflag[i] = (i == 0 || i == n) ? 1 : 0;
+  __syncthreads();
+  if (n > 16) {
+    int sp = 0;
+    if (lane == 0) { stk[0] = 0; stk[1] = n; stk[2] = 2 * orbx_sort::floor_log2(n); }
+    sp = 1;
+    __syncthreads();
+    while (sp > 0) {
+      --sp;
+      int first = stk[3 * sp], last = stk[3 * sp + 1], depth = stk[3 * sp + 2];
+      __syncthreads();
+      while (last - first > 16) {
+        if (depth == 0) {
+          if (lane == 0) orbx_sort::heap_sort_range(v, first, last);
+          __syncthreads();
+          break;
+        }
+        --depth;
+        const int mid = first + (last - first) / 2;
+        if (lane == 0) orbx_sort::move_median_to_first(v, first, first + 1, mid, last - 1);
+        __syncthreads();
+        const orbx_sort::elem_t P = v[first];
+        const int lo = first + 1, hi = last;
+        int nA = 0, nB = 0;
+        for (int base = lo; base < hi; base += 64) {
+          const int i = base + lane;
+          const bool fl = i < hi && !less(v[i], P);
+          const unsigned long long mask = __ballot(fl);
+          if (fl) posA[nA + mbcnt64(mask)] = (unsigned short)i;
+          nA += __popcll(mask);
+        }
+        for (int base = hi - 1; base >= lo; base -= 64) {
+          const int i = base - lane;
+          const bool fl = i >= lo && !less(P, v[i]);
+          const unsigned long long mask = __ballot(fl);
+          if (fl) posB[nB + mbcnt64(mask)] = (unsigned short)i;
+          nB += __popcll(mask);
+        }
+        __syncthreads();
+        const int kmax = min(nA, nB);
+        int kstar = 0;
+        for (int base = 0; base < kmax; base += 64) {
+          const int k = base + lane;
+          const bool ok = k < kmax && posA[k] < posB[k];
+          const unsigned long long mask = __ballot(ok);
+          const int c = __popcll(mask);
+          kstar += c;
+          if (c < 64) break;
+        }
+        for (int k = lane; k < kstar; k += 64) {
+          const int a = posA[k], b = posB[k];
+          const orbx_sort::elem_t t = v[a];
+          v[a] = v[b];
+          v[b] = t;
+        }
+        const int ia = kstar < nA ? (int)posA[kstar] : 0x7fffffff;
+        const int ib = kstar > 0 ? (int)posB[kstar - 1] : 0x7fffffff;
+        const int cut = min(ia, ib);
+        if (lane == 0) {
+          stk[3 * sp] = cut; stk[3 * sp + 1] = last; stk[3 * sp + 2] = depth;
+          segflag[cut] = 1;
+        }
+        ++sp;
+        last = cut;
+        __syncthreads();
+      }
+    }
+  }
+  // stable sort inside every segment [s, e)
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + lane;
+    if (i < n) {
+      int s0 = i;
+      while (!segflag[s0]) --s0;
+      int e = i + 1;
+      while (!segflag[e]) ++e;
+      const orbx_sort::elem_t me = v[i];
+      int rank = s0;
+      for (int j = s0; j < e; ++j) {
+        const orbx_sort::elem_t o = v[j];
+        rank += (less(o, me) || (!less(me, o) && j < i)) ? 1 : 0;
+      }
+      tmp[rank] = me;
+    }
+  }
+  __syncthreads();
+  for (int i = lane; i < n; i += 64) v[i] = tmp[i];
+  __syncthreads();
+}
+
+// Test hook: sorts n records in LDS with oct_sort and returns them.
+__global__ __launch_bounds__(64) void k_debug_sort(orbx_sort::elem_t* data, int n) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  orbx_sort::elem_t* v = (orbx_sort::elem_t*)smem;
+  orbx_sort::elem_t* tmp = v + n;
+  int* stk = (int*)(tmp + n);
+  unsigned short* posA = (unsigned short*)(stk + 192);
+  unsigned short* posB = posA + n;
+  unsigned char* segflag = (unsigned char*)(posB + n);
+  for (int i = threadIdx.x; i < n; i += 64) v[i] = data[i];
+  __syncthreads();
+  oct_sort(v, n, posA, posB, segflag, tmp, stk);
+  for (int i = threadIdx.x; i < n; i += 64) data[i] = v[i];
+}
+
 __global__ __launch_bounds__(64) void k_octree(const Plan* __restrict__ plan,
                                                const uint32_t* __restrict__ cand,
                                                const int* __restrict__ cellCount,
                                                uint32_t* __restrict__ flatA,
                                                uint32_t* __restrict__ flatB,
                                                uint32_t* __restrict__ sel,
-                                               int* __restrict__ selCount) {
+                                               int* __restrict__ selCount, int f0) {
   extern __shared__ __align__(16) uint8_t smem[];
-  const int l = blockIdx.x, f = blockIdx.y;
+  const int l = blockIdx.x, f = blockIdx.y + f0;
   const int lane = lane_id();
   const LevelDesc& L = plan->lv[l];
   const int cap = plan->oct_nodes_cap;
-  QNode* cur = (QNode*)smem;
-  QNode* nxt = cur + cap;
-  QNode* newch = nxt + cap;
-  orbx_sort::elem_t* rec = (orbx_sort::elem_t*)(newch + cap);
-  int* cellpref = (int*)(rec + cap);
-  __shared__ int rootCnt[ORBX_MAX_ROOTS];
-
   OctState st;
-  st.newch = newch;
-  st.bufA = flatA + (size_t)f * plan->flat_frame + L.flat_off;
-  st.bufB = flatB + (size_t)f * plan->flat_frame + L.flat_off;
+  st.cnt4 = (int4*)smem;                                    // 16-byte aligned first
+  st.cur = (QNode*)(st.cnt4 + cap);
+  st.nxt = st.cur + cap;
+  st.newch = st.nxt + cap;
+  orbx_sort::elem_t* rec = (orbx_sort::elem_t*)(st.newch + cap);
+  st.cbase = (int*)(rec + cap);
+  int* cellpref = st.cbase + cap;
+  uint32_t* ldsKeys = (uint32_t*)(cellpref + plan->oct_cells_max + 1);
+  st.ord = (unsigned short*)(ldsKeys + 2 * plan->oct_keys_lds);
+  __shared__ int rootCnt[ORBX_MAX_ROOTS];
 
   // ---- candidate order = cell-row-major, then (y, x) inside a cell ---------
   const int nc = L.ncx * L.ncy;
@@ -691,30 +926,47 @@ __global__ __launch_bounds__(64) void k_octree(const Plan* __restrict__ plan,
   }
   if (lane == 0) cellpref[nc] = total;
   if (lane < ORBX_MAX_ROOTS) rootCnt[lane] = 0;
+  if (total <= plan->oct_keys_lds) {
+    st.bufA = ldsKeys;
+    st.bufB = ldsKeys + plan->oct_keys_lds;
+  } else {
+    st.bufA = flatA + (size_t)f * plan->flat_frame + L.flat_off;
+    st.bufB = flatB + (size_t)f * plan->flat_frame + L.flat_off;
+  }
   __syncthreads();
 
   // flatten into B and count keys per root: root = int(x / hX) (extractor.cc:571-574)
   const uint32_t* candL = cand + (size_t)f * plan->cand_frame + L.cand_off;
   const int nroots = L.n_roots;
   const float hX = L.hX;
-  for (int base = 0; base < total; base += 64) {
-    const int i = base + lane;
-    const bool valid = i < total;
-    uint32_t key = 0;
-    int r = -1;
-    if (valid) {
-      int lo = 0, hi = nc;  // largest c with cellpref[c] <= i
+  // four chunks per trip so that the (global) candidate loads of a trip are in flight together
+  for (int base = 0; base < total; base += 256) {
+    uint32_t key[4];
+    bool valid[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = base + u * 64 + lane;
+      valid[u] = i < total;
+      const int ic = valid[u] ? i : total - 1;
+      int lo = 0, hi = nc;  // largest c with cellpref[c] <= ic
       while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
-        if (cellpref[mid] <= i) lo = mid; else hi = mid;
+        if (cellpref[mid] <= ic) lo = mid; else hi = mid;
       }
-      key = candL[(size_t)lo * L.cand_cap_cell + (i - cellpref[lo])];
-      st.bufB[i] = key;
-      r = (int)__fdiv_rn((float)(key & 0xFFF), hX);
+      key[u] = candL[(size_t)lo * L.cand_cap_cell + (ic - cellpref[lo])];
     }
-    for (int rr = 0; rr < nroots; ++rr) {
-      const unsigned long long m = __ballot(r == rr);
-      if (lane == 0 && m) rootCnt[rr] += __popcll(m);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = base + u * 64 + lane;
+      int r = -1;
+      if (valid[u]) {
+        st.bufB[i] = key[u];
+        r = (int)__fdiv_rn((float)(key[u] & 0xFFF), hX);
+      }
+      for (int rr = 0; rr < nroots; ++rr) {
+        const unsigned long long m = __ballot(r == rr);
+        if (lane == 0 && m) rootCnt[rr] += __popcll(m);
+      }
     }
   }
   __syncthreads();
@@ -758,7 +1010,7 @@ __global__ __launch_bounds__(64) void k_octree(const Plan* __restrict__ plan,
           nd.bry = (short)hgt;
           nd.start = acc;
           nd.cnt = c;  // buffer A
-          cur[n] = nd;
+          st.cur[n] = nd;
         }
         ++n;
       }
@@ -772,40 +1024,46 @@ __global__ __launch_bounds__(64) void k_octree(const Plan* __restrict__ plan,
   bool finish = false;
   while (!finish) {
     int prevSize = n;
-    st.nch = 0;
-    st.nToExpand = 0;
-    for (int p = 0; p < n; ++p) {
-      const QNode nd = cur[p];
-      if (qcount(nd) <= 1) continue;
-      split_node(nd, st);
-      if (lane == 0) cur[p].cnt = 0;
+    // whole-level pass (extractor.cc:606-657): every node with more than one key, list order
+    int m = 0;
+    for (int base = 0; base < n; base += 64) {
+      const int p = base + lane;
+      const bool exp = p < n && qcount(st.cur[p]) > 1;
+      const unsigned long long mask = __ballot(exp);
+      if (exp) st.ord[m + mbcnt64(mask)] = (unsigned short)p;
+      m += __popcll(mask);
     }
     __syncthreads();
-    n = rebuild_list(cur, n, newch, st.nch, nxt);
-    nrec = build_records(newch, st.nch, rec);
-    { QNode* t = cur; cur = nxt; nxt = t; }
+    oct_count(st, m);
+    __syncthreads();
+    int nch, nToExpand;
+    oct_place(st, m, n, N, false, &nch, &nToExpand);
+    __syncthreads();
+    oct_scatter(st, m);
+    __syncthreads();
+    n = rebuild_list(st.cur, n, st.newch, nch, st.nxt);
+    nrec = build_records(st.newch, nch, rec);
+    { QNode* t = st.cur; st.cur = st.nxt; st.nxt = t; }
     __syncthreads();
     if (n >= N || n == prevSize) {
       finish = true;
-    } else if (n + st.nToExpand * 3 > N) {
+    } else if (n + nToExpand * 3 > N) {
+      // final rounds (extractor.cc:665-721): largest nodes first, stop at N nodes
       while (!finish) {
         prevSize = n;
-        if (lane == 0) orbx_sort::std_sort(rec, nrec);
+        oct_sort(rec, nrec, st.ord, (unsigned short*)st.cbase, (unsigned char*)st.newch,
+                 (orbx_sort::elem_t*)st.cnt4, (int*)st.nxt);
+        for (int t = lane; t < nrec; t += 64) st.ord[t] = (unsigned short)(uint32_t)rec[nrec - 1 - t];
         __syncthreads();
-        st.nch = 0;
-        st.nToExpand = 0;
-        int running = n;
-        for (int j = nrec - 1; j >= 0; --j) {
-          const int pos = (int)(uint32_t)rec[j];
-          const QNode nd = cur[pos];
-          running += split_node(nd, st) - 1;
-          if (lane == 0) cur[pos].cnt = 0;
-          if (running >= N) break;
-        }
+        oct_count(st, nrec);
         __syncthreads();
-        n = rebuild_list(cur, n, newch, st.nch, nxt);
-        nrec = build_records(newch, st.nch, rec);
-        { QNode* t = cur; cur = nxt; nxt = t; }
+        const int mEff = oct_place(st, nrec, n, N, true, &nch, &nToExpand);
+        __syncthreads();
+        oct_scatter(st, mEff);
+        __syncthreads();
+        n = rebuild_list(st.cur, n, st.newch, nch, st.nxt);
+        nrec = build_records(st.newch, nch, rec);
+        { QNode* t = st.cur; st.cur = st.nxt; st.nxt = t; }
         __syncthreads();
         if (n >= N || n == prevSize) finish = true;
       }
@@ -815,7 +1073,7 @@ __global__ __launch_bounds__(64) void k_octree(const Plan* __restrict__ plan,
   // best key per node: highest score, first one wins ties (extractor.cc:726-742)
   uint32_t* out = sel + (size_t)f * plan->sel_frame + L.sel_off;
   for (int p = lane; p < n; p += 64) {
-    const QNode nd = cur[p];
+    const QNode nd = st.cur[p];
     const uint32_t* keys = (((unsigned)nd.cnt >> 31) ? st.bufB : st.bufA) + nd.start;
     const int cnt = qcount(nd);
     uint32_t best = keys[0];
@@ -839,10 +1097,11 @@ __global__ __launch_bounds__(256) void k_assemble(const Plan* __restrict__ plan,
                                                   const int* __restrict__ selCount, int lap0,
                                                   int lap1, float* __restrict__ kps,
                                                   WorkItem* __restrict__ work,
-                                                  int* __restrict__ nOut, int* __restrict__ monoOut) {
+                                                  int* __restrict__ nOut, int* __restrict__ monoOut,
+                                                  int f0) {
   __shared__ int lvOff[ORBX_MAX_LEVELS + 1];
   __shared__ int waveCnt[4];
-  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int f = blockIdx.x + f0, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nl = plan->nlevels;
   if (tid == 0) {
     int acc = 0;
@@ -944,8 +1203,8 @@ __device__ __forceinline__ void blur_hrow(const uint8_t* rowp, uint32_t (&h)[4])
 
 __global__ __launch_bounds__(256) void k_blur(const Plan* __restrict__ plan,
                                               const uint8_t* __restrict__ pyr,
-                                              uint8_t* __restrict__ blur) {
-  const int f = blockIdx.y;
+                                              uint8_t* __restrict__ blur, int f0) {
+  const int f = blockIdx.y + f0;
   const int tg = blockIdx.x;
   int l = 0;
   while (l + 1 < plan->nlevels && tg >= plan->lv[l + 1].tile_first) ++l;
@@ -1046,8 +1305,8 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Plan* __restrict_
                                                          const WorkItem* __restrict__ work,
                                                          const int* __restrict__ nOut,
                                                          float* __restrict__ kps,
-                                                         uint8_t* __restrict__ desc) {
-  const int f = blockIdx.y;
+                                                         uint8_t* __restrict__ desc, int f0) {
+  const int f = blockIdx.y + f0;
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, j16 = lane & 15;
   const int n = nOut[f];
@@ -1118,17 +1377,17 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Plan* __restrict_
 }
 
 // ---------------------------------------------------------------------------
-// launch functions (host)
+// launch functions (host): frames [f0, f0 + nframes) of the batch on stream s
 // ---------------------------------------------------------------------------
 void launch_pyramid(const Plan& hp, const uint8_t* d_img, int istride, size_t iframe, uint8_t* d_pyr,
-                    int nframes, hipStream_t s) {
+                    int f0, int nframes, hipStream_t s) {
   const dim3 blk(64, 4);
   {
     const LevelDesc& L = hp.lv[0];
     const int nbx = (L.pstride / 16 + 63) / 64;
     dim3 grid(nbx + 1, (L.prows + 4 * L0_ROWS - 1) / (4 * L0_ROWS), nframes);
     hipLaunchKernelGGL(k_pyr_level0, grid, blk, 0, s, d_img, hp.W, hp.H, istride, iframe,
-                       d_pyr + L.pyr_off, L.pstride, L.prows, L.pyr_plane, nbx);
+                       d_pyr + L.pyr_off, L.pstride, L.prows, L.pyr_plane, nbx, f0);
   }
   for (int l = 1; l < hp.nlevels; ++l) {
     const LevelDesc& S = hp.lv[l - 1];
@@ -1138,7 +1397,7 @@ void launch_pyramid(const Plan& hp, const uint8_t* d_img, int istride, size_t if
     hipLaunchKernelGGL(k_pyr_resize, grid, blk, 0, s, d_pyr + S.pyr_off,
                        S.pstride, S.pyr_plane, d_pyr + L.pyr_off, L.pstride, L.prows, L.pyr_plane,
                        L.w + 2 * ORBX_EDGE, L.xtab, L.ytab, L.colrec, L.bcols,
-                       L.n_bcols, nbx);
+                       L.n_bcols, nbx, f0);
   }
 }
 
@@ -1148,51 +1407,59 @@ size_t fast_lds_bytes(const Plan& hp, int ts) {
 }
 
 void launch_fast(const Plan& hp, const Plan* dp, const uint8_t* d_pyr, uint32_t* d_cand,
-                 int* d_cellCount, int nframes, hipStream_t s) {
+                 int* d_cellCount, int f0, int nframes, hipStream_t s) {
   dim3 grid(hp.cells_per_frame, nframes);
   const int ts = hp.fast_ts;
   const size_t lds = fast_lds_bytes(hp, ts);
   if (ts == 48)
-    hipLaunchKernelGGL(k_fast_cells<48>, grid, dim3(64), lds, s, dp, d_pyr, d_cand, d_cellCount);
+    hipLaunchKernelGGL(k_fast_cells<48>, grid, dim3(64), lds, s, dp, d_pyr, d_cand, d_cellCount, f0);
   else if (ts == 64)
-    hipLaunchKernelGGL(k_fast_cells<64>, grid, dim3(64), lds, s, dp, d_pyr, d_cand, d_cellCount);
+    hipLaunchKernelGGL(k_fast_cells<64>, grid, dim3(64), lds, s, dp, d_pyr, d_cand, d_cellCount, f0);
   else
-    hipLaunchKernelGGL(k_fast_cells<80>, grid, dim3(64), lds, s, dp, d_pyr, d_cand, d_cellCount);
+    hipLaunchKernelGGL(k_fast_cells<80>, grid, dim3(64), lds, s, dp, d_pyr, d_cand, d_cellCount, f0);
 }
 
 size_t octree_lds_bytes(const Plan& hp) {
-  return (size_t)hp.oct_nodes_cap * (3 * sizeof(QNode) + sizeof(orbx_sort::elem_t)) +
-         (size_t)(hp.oct_cells_max + 1) * sizeof(int);
+  return (size_t)hp.oct_nodes_cap * (sizeof(int4) + 3 * sizeof(QNode) + sizeof(orbx_sort::elem_t) +
+                                      sizeof(int) + sizeof(unsigned short)) +
+         (size_t)(hp.oct_cells_max + 1) * sizeof(int) + (size_t)hp.oct_keys_lds * 2 * sizeof(uint32_t) + 16;
 }
 
 void launch_octree(const Plan& hp, const Plan* dp, const uint32_t* d_cand, const int* d_cellCount,
                    uint32_t* d_flatA, uint32_t* d_flatB, uint32_t* d_sel, int* d_selCount,
-                   int nframes, hipStream_t s) {
+                   int f0, int nframes, hipStream_t s) {
   dim3 grid(hp.nlevels, nframes);
   hipLaunchKernelGGL(k_octree, grid, dim3(64), octree_lds_bytes(hp), s, dp, d_cand, d_cellCount,
-                     d_flatA, d_flatB, d_sel, d_selCount);
+                     d_flatA, d_flatB, d_sel, d_selCount, f0);
 }
 
 void launch_assemble(const Plan& hp, const Plan* dp, const uint32_t* d_sel, const int* d_selCount,
                      int lap0, int lap1, float* d_kps, WorkItem* d_work, int* d_n, int* d_mono,
-                     int nframes, hipStream_t s) {
+                     int f0, int nframes, hipStream_t s) {
   (void)hp;
   hipLaunchKernelGGL(k_assemble, dim3(nframes), dim3(256), 0, s, dp, d_sel, d_selCount, lap0, lap1,
-                     d_kps, d_work, d_n, d_mono);
+                     d_kps, d_work, d_n, d_mono, f0);
 }
 
-void launch_blur(const Plan& hp, const Plan* dp, const uint8_t* d_pyr, uint8_t* d_blur, int nframes,
-                 hipStream_t s) {
+void launch_blur(const Plan& hp, const Plan* dp, const uint8_t* d_pyr, uint8_t* d_blur, int f0,
+                 int nframes, hipStream_t s) {
   dim3 grid(hp.tiles_per_frame, nframes);
-  hipLaunchKernelGGL(k_blur, grid, dim3(256), 0, s, dp, d_pyr, d_blur);
+  hipLaunchKernelGGL(k_blur, grid, dim3(256), 0, s, dp, d_pyr, d_blur, f0);
 }
 
 void launch_describe(const Plan& hp, const Plan* dp, const uint8_t* d_pyr, const uint8_t* d_blur,
                      const WorkItem* d_work, const int* d_n, float* d_kps, uint8_t* d_desc,
-                     int nframes, hipStream_t s) {
+                     int f0, int nframes, hipStream_t s) {
   dim3 grid((hp.kp_cap + 15) / 16, nframes);
   hipLaunchKernelGGL(k_orient_describe, grid, dim3(256), 0, s, dp, d_pyr, d_blur, d_work, d_n, d_kps,
-                     d_desc);
+                     d_desc, f0);
+}
+
+int launch_debug_sort(uint64_t* d_data, int n, hipStream_t s) {
+  const size_t lds = (size_t)n * 16 + 192 * 4 + (size_t)n * 4 + n + 32;
+  if (lds > 64 * 1024 - 64) return -1;
+  hipLaunchKernelGGL(k_debug_sort, dim3(1), dim3(64), lds, s, (orbx_sort::elem_t*)d_data, n);
+  return 0;
 }
 
 int octree_set_lds_limit(const Plan& hp) {

@@ -83,6 +83,7 @@ struct Plan {
   int fast_ts, fast_tile_rows, fast_mm_rows, fast_qcap, fast_words;
   int oct_nodes_cap;     // quadtree node slots (max over levels)
   int oct_cells_max;     // max cells in one level
+  int oct_keys_lds;      // keys per LDS key buffer of k_octree (0 = always use global memory)
   int umax[16];          // circular patch row half-widths (extractor.cc:448-462)
   LevelDesc lv[ORBX_MAX_LEVELS];
 };

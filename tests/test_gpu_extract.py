@@ -123,3 +123,31 @@ def test_errors():
     with pytest.raises(orbx.OrbxError) as e:
         ex(np.zeros((100, 100), np.uint8))
     assert e.value.status == -2
+
+
+def test_device_sort_matches_std_sort(oracle):
+    """The quadtree kernel's wave-parallel sort must give std::sort's permutation, ties included."""
+    import ctypes as C
+    from orb_slam3_amd._lib import lib, check, ptr
+    rng = np.random.default_rng(17)
+    cases = []
+    for n in [1, 2, 15, 16, 17, 33, 64, 65, 100, 128, 200, 233, 500, 1000, 2200, 3000]:
+        for nkeys in (1, 2, 5, 40, 100000):
+            for mode in range(4):
+                size = rng.integers(2, 2 + nkeys, n)
+                ulx = rng.integers(0, 1 + nkeys // 3, n)
+                if mode == 1:
+                    size = np.arange(n) % nkeys + 2
+                if mode == 2:
+                    size = (n - np.arange(n)) % nkeys + 2
+                if mode == 3:
+                    size = np.where(np.arange(n) < n // 2, np.arange(n) % nkeys, (n - np.arange(n)) % nkeys) + 2
+                cases.append((size.astype(np.int32), (ulx % 4096).astype(np.int32)))
+    for size, ulx in cases:
+        n = len(size)
+        perm_ref = oracle.sort_sized_nodes(size, ulx)
+        rec = ((size.astype(np.uint64) << np.uint64(12) | ulx.astype(np.uint64)) << np.uint64(32)) | np.arange(n, dtype=np.uint64)
+        rec = np.ascontiguousarray(rec)
+        check(lib().orbx_debug_sort_records(0, ptr(rec), n))
+        perm = (rec & np.uint64(0xFFFFFFFF)).astype(np.int32)
+        assert np.array_equal(perm, perm_ref), (n, size[:8], ulx[:8])

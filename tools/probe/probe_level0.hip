@@ -83,7 +83,7 @@ int main() {
   time("level0", [&] {
     const int nbx = (pstride / 16 + 63) / 64;
     dim3 grid(nbx + 1, (prows + 4 * L0_ROWS - 1) / (4 * L0_ROWS), B);
-    hipLaunchKernelGGL(orbx::k_pyr_level0, grid, dim3(64, 4), 0, 0, img, W, H, W, iframe, dst, pstride, prows, dplane, nbx);
+    hipLaunchKernelGGL(orbx::k_pyr_level0, grid, dim3(64, 4), 0, 0, img, W, H, W, iframe, dst, pstride, prows, dplane, nbx, 0);
   });
 #define RUNV(R, M) time("l0v rows=" #R " mode=" #M, [&] { dim3 grid((pstride / 16 + 63) / 64, (prows + 4 * R - 1) / (4 * R), B); \
     hipLaunchKernelGGL((k_l0v<R, M>), grid, dim3(64, 4), 0, 0, img, W, H, W, iframe, dst, pstride, prows, dplane); });
