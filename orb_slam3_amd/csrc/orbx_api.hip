@@ -386,7 +386,7 @@ int orbx_extractor::ensurePlan(int W, int H) {
   HIP_TRY(hipMemcpy(dp, &hp, sizeof(Plan), hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc((void**)&d_img, (size_t)B * W * H));
   HIP_TRY(hipMalloc((void**)&d_pyr, pyrOff));
-  HIP_TRY(hipMalloc((void**)&d_blur, blurOff));
+  HIP_TRY(hipMalloc((void**)&d_blur, blurOff + 256));  // window loads may overrun a row end by a few bytes
   HIP_TRY(hipMalloc((void**)&d_cand, (size_t)B * hp.cand_frame * 4));
   HIP_TRY(hipMalloc((void**)&d_cellCount, (size_t)B * hp.cells_per_frame * 4));
   HIP_TRY(hipMalloc((void**)&d_flatA, (size_t)B * hp.flat_frame * 4));

@@ -1297,8 +1297,12 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 
 // 16 lanes per keypoint, 4 keypoints per wave, 16 per block.
 //  * moments: lane j of a group owns patch columns u = 2j-15 and 2j-14 and walks the
-//    31 rows (62 independent byte loads in flight per lane);
+//    31 rows of the patch, which is staged in LDS by row-wise dword loads;
 //  * descriptor: lane j evaluates tests 16j .. 16j+15 = descriptor bytes 2j, 2j+1.
+#define DESC_WIN_DW 370   // 37 rows x 10 dwords
+#define DESC_STAGE 24     // dwords per lane (16 lanes per keypoint)
+#define IC_WIN_DW 279     // 31 rows x 9 dwords
+#define IC_STAGE 18
 __global__ __launch_bounds__(256) void k_orient_describe(const Plan* __restrict__ plan,
                                                          const uint8_t* __restrict__ pyr,
                                                          const uint8_t* __restrict__ blur,
@@ -1320,22 +1324,44 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Plan* __restrict_
   const int ps = L.pstride, bs = L.bstride;
 
   // ---- IC_Angle on the un-blurred level (extractor.cc:75-99) ----------------
-  const uint8_t* center = pyr + L.pyr_off + (size_t)f * L.pyr_plane +
-                          (size_t)(cy + ORBX_EDGE) * ps + (cx + ORBX_EDGE);
+  // the 31 x 31 patch goes through the same LDS window as the blurred one below
+  __shared__ uint32_t sWin[16][DESC_WIN_DW];
+  const int slotInBlock = (int)(threadIdx.x >> 6) * 4 + g;
   const int u0 = 2 * j16 - 15, u1 = u0 + 1;
   const int au0 = u0 < 0 ? -u0 : u0, au1 = u1 < 0 ? -u1 : u1;
-  int um[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) um[i] = plan->umax[i];
   int m10 = 0, m01 = 0;
+  {
+    const int px0 = (cx + ORBX_EDGE - 15) & ~3;   // padded column of the window's first dword
+    const uint8_t* pbase = pyr + L.pyr_off + (size_t)f * L.pyr_plane + (size_t)(cy + ORBX_EDGE - 15) * ps + px0;
+    uint32_t st2[IC_STAGE];
 #pragma unroll
-  for (int v = -15; v <= 15; ++v) {
-    const int lim = um[v < 0 ? -v : v];
-    const uint8_t* rp = center + v * ps;
-    const int a = au0 <= lim ? (int)rp[u0] : 0;
-    const int b = au1 <= lim ? (int)rp[u1] : 0;   // u1 = 16 never passes (lim <= 15)
-    m10 += __mul24(u0, a) + __mul24(u1, b);
-    m01 += __mul24(v, a + b);
+    for (int u = 0; u < IC_STAGE; ++u) {
+      const int idx = min(j16 + 16 * u, IC_WIN_DW - 1);
+      const int r = idx / 9, c9 = idx - r * 9;
+      st2[u] = *(const uint32_t*)(pbase + (size_t)r * ps + 4 * c9);
+    }
+    int um[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) um[i] = plan->umax[i];
+#pragma unroll
+    for (int u = 0; u < IC_STAGE; ++u) {
+      const int idx = j16 + 16 * u;
+      if (idx < IC_WIN_DW) sWin[slotInBlock][idx] = st2[u];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    const uint8_t* center = (const uint8_t*)sWin[slotInBlock] + 15 * 36 + (cx + ORBX_EDGE - px0);
+#pragma unroll
+    for (int v = -15; v <= 15; ++v) {
+      const int lim = um[v < 0 ? -v : v];
+      const uint8_t* rp = center + v * 36;
+      const int a = au0 <= lim ? (int)rp[u0] : 0;
+      const int b = au1 <= lim ? (int)rp[u1] : 0;   // u1 = 16 never passes (lim <= 15)
+      m10 += __mul24(u0, a) + __mul24(u1, b);
+      m01 += __mul24(v, a + b);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
   }
 #pragma unroll
   for (int d = 8; d >= 1; d >>= 1) {
@@ -1345,10 +1371,29 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Plan* __restrict_
   const float angle = fast_atan2_deg((float)m01, (float)m10);
 
   // ---- steered BRIEF on the blurred level (extractor.cc:102-145) ------------
+  // The 37 x 37 window the 512 sample points can fall into (reach 18) is staged in LDS
+  // with row-wise dword loads (issued before the trigonometry so they overlap it); the
+  // rotated samples are then LDS byte reads instead of scattered global gathers.
+  const int bx0 = (cx - 18) & ~3;
+  const uint8_t* wbase = blur + L.blur_off + (size_t)f * L.blur_plane + (size_t)(cy - 18) * bs + bx0;
+  uint32_t stage[DESC_STAGE];
+#pragma unroll
+  for (int u = 0; u < DESC_STAGE; ++u) {
+    const int idx = min(j16 + 16 * u, DESC_WIN_DW - 1);
+    const int r = idx / 10, c10 = idx - r * 10;
+    stage[u] = *(const uint32_t*)(wbase + (size_t)r * bs + 4 * c10);
+  }
   const float factorPI = (float)(3.1415926535897932384626433832795 / 180.0);
   const float rad = __fmul_rn(angle, factorPI);
   const float a = (float)cos((double)rad), b = (float)sin((double)rad);
-  const uint8_t* bc = blur + L.blur_off + (size_t)f * L.blur_plane + (size_t)cy * bs + cx;
+#pragma unroll
+  for (int u = 0; u < DESC_STAGE; ++u) {
+    const int idx = j16 + 16 * u;
+    if (idx < DESC_WIN_DW) sWin[slotInBlock][idx] = stage[u];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  const uint8_t* bc = (const uint8_t*)sWin[slotInBlock] + 18 * 40 + (cx - bx0);
   const uint4* pp = (const uint4*)(c_pattern + 64 * j16);
   uint32_t bits = 0;
 #pragma unroll
@@ -1364,8 +1409,8 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Plan* __restrict_
       const int q0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
       const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
       const int q1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-      const int t0 = bc[r0 * bs + q0];
-      const int t1 = bc[r1 * bs + q1];
+      const int t0 = bc[r0 * 40 + q0];
+      const int t1 = bc[r1 * 40 + q1];
       bits |= (t0 < t1 ? 1u : 0u) << (q * 4 + e);
     }
   }
