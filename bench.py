@@ -88,12 +88,46 @@ def cpu_baseline(frames, seconds_budget=15.0):
             "single_thread_ms_per_frame": one * 1e3}
 
 
+def hamming_bench(torch, orbx, dev, nq=65536, nt=262144, reps=3):
+    """Secondary metric: brute-force Hamming 2-NN pairs/s on device-resident descriptors
+    (uniform random 256-bit rows).  Roofline = VALU: 16 lane-ops per pair (8 xor + 8 bcnt)
+    against 256 CUs x 64 lanes x 2.4 GHz."""
+    import ctypes as C
+    from orb_slam3_amd._lib import lib, check
+    q = torch.randint(0, 256, (nq, 32), dtype=torch.uint8, device=dev)
+    t = torch.randint(0, 256, (nt, 32), dtype=torch.uint8, device=dev)
+    idx = torch.empty((nq, 2), dtype=torch.int32, device=dev)
+    dst = torch.empty((nq, 2), dtype=torch.int16, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def run():
+        check(lib().orbx_knn2_device(C.c_void_p(q.data_ptr()), nq, C.c_void_p(t.data_ptr()), nt, 0,
+                                     C.c_void_p(idx.data_ptr()), C.c_void_p(dst.data_ptr()),
+                                     C.c_void_p(stream)))
+    run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) * 1e-3 / reps
+    pairs = nq * nt / sec
+    peak_ops = 256 * 64 * 2.4e9
+    return {"metric": "Hamming pairs/s (brute-force 2-NN)", "value": pairs, "unit": "pairs/s",
+            "queries": nq, "train": nt, "ms": sec * 1e3,
+            "roofline": {"bound": "valu", "achieved": pairs * 16 / 1e12, "peak": peak_ops / 1e12,
+                         "unit": "T lane-ops/s", "frac": pairs * 16 / peak_ops}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=512, help="frames per step per GPU")
+    ap.add_argument("--no-match", action="store_true", help="skip the Hamming 2-NN leg")
     ap.add_argument("--distinct", type=int, default=32, help="distinct synthetic frames (tiled to the batch)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     args = ap.parse_args()
@@ -181,6 +215,8 @@ def main():
             "stage_ms_per_step": acc,
             "whole_frame_roofline_frac": fps / world * frame_bytes / (HBM_PEAK_GBS * 1e9),
         }
+        if not args.no_match:
+            out["hamming"] = hamming_bench(torch, orbx, dev)
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames)
             out["gpu_over_cpu"] = fps / out["cpu_baseline"]["value"]
