@@ -291,7 +291,7 @@ int orbx_extractor::ensurePlan(int W, int H) {
   hp.fast_ts = cwMax <= 40 ? 48 : (cwMax <= 56 ? 64 : 80);
   hp.fast_tile_rows = chMax + 7;
   hp.fast_mm_rows = chMax + 2;
-  hp.fast_qcap = (cwMax * chMax + 7) / 8 * 8;
+  hp.fast_qcap = std::min(512, (cwMax * chMax + 7) / 8 * 8);  // survivors queued per cell; more -> per-pixel path
   hp.fast_words = (cwMax * chMax + 31) / 32;
   hp.oct_nodes_cap = nodesCap;
   hp.oct_cells_max = cellsMax;

@@ -246,7 +246,8 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const uint8_t* __restrict__ 
 //   2. quick rejection for every pixel, 8 pixels (4 columns x 2 rows) per lane
 //      and two pixels per instruction (packed 16-bit min/max): a 9-arc holds
 //      one pixel of each of the 8 opposite ring pairs, so a corner needs
-//      max_k min(I_k, I_k+8) < v - t  or  min_k max(I_k, I_k+8) > v + t;
+//      max_k min(I_k, I_k+8) < v - t  or  min_k max(I_k, I_k+8) > v + t
+//      (evaluated over the 4 axis/diagonal pairs);
 //      survivors (a few percent of the pixels) are queued in LDS;
 //   3. the exact m for queued pixels only, one pixel per lane;
 //   4. suppression + threshold choice + ordered output through bit masks in
@@ -330,23 +331,17 @@ __device__ __forceinline__ uint32_t pick2(const uint32_t (&row)[3]) {
 template <int WR, int C>
 __device__ __forceinline__ uint32_t quick_pair(const uint32_t (&R)[8][3], uint32_t tt) {
   const uint32_t v = pick2<C>(R[WR]);
-  // opposite ring pairs (dx,dy) / (-dx,-dy)
+  // four of the eight opposite ring pairs (dx,dy) / (-dx,-dy): the axes and the diagonals.
+  // Any subset of the pairs is a valid necessary condition; on edge-like structure these
+  // four reject almost as much as all eight at half the cost.
   const uint32_t a0 = pick2<C + 0>(R[WR + 3]), b0 = pick2<C + 0>(R[WR - 3]);
-  const uint32_t a1 = pick2<C + 1>(R[WR + 3]), b1 = pick2<C - 1>(R[WR - 3]);
   const uint32_t a2 = pick2<C + 2>(R[WR + 2]), b2 = pick2<C - 2>(R[WR - 2]);
-  const uint32_t a3 = pick2<C + 3>(R[WR + 1]), b3 = pick2<C - 3>(R[WR - 1]);
   const uint32_t a4 = pick2<C + 3>(R[WR]),     b4 = pick2<C - 3>(R[WR]);
-  const uint32_t a5 = pick2<C + 3>(R[WR - 1]), b5 = pick2<C - 3>(R[WR + 1]);
   const uint32_t a6 = pick2<C + 2>(R[WR - 2]), b6 = pick2<C - 2>(R[WR + 2]);
-  const uint32_t a7 = pick2<C + 1>(R[WR - 3]), b7 = pick2<C - 1>(R[WR + 3]);
   uint32_t lo = pk_min_u16(a0, b0), hi = pk_max_u16(a0, b0);
-  lo = pk_max_u16(lo, pk_min_u16(a1, b1)); hi = pk_min_u16(hi, pk_max_u16(a1, b1));
   lo = pk_max_u16(lo, pk_min_u16(a2, b2)); hi = pk_min_u16(hi, pk_max_u16(a2, b2));
-  lo = pk_max_u16(lo, pk_min_u16(a3, b3)); hi = pk_min_u16(hi, pk_max_u16(a3, b3));
   lo = pk_max_u16(lo, pk_min_u16(a4, b4)); hi = pk_min_u16(hi, pk_max_u16(a4, b4));
-  lo = pk_max_u16(lo, pk_min_u16(a5, b5)); hi = pk_min_u16(hi, pk_max_u16(a5, b5));
   lo = pk_max_u16(lo, pk_min_u16(a6, b6)); hi = pk_min_u16(hi, pk_max_u16(a6, b6));
-  lo = pk_max_u16(lo, pk_min_u16(a7, b7)); hi = pk_min_u16(hi, pk_max_u16(a7, b7));
   // dark arc possible: lo + t < v ; bright arc possible: hi > v + t
   const uint32_t s1 = pk_sub_i16(v, pk_add_u16(lo, tt));
   const uint32_t s2 = pk_sub_i16(hi, pk_add_u16(v, tt));
@@ -406,6 +401,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Plan* __restrict__ plan
   const uint32_t tt = (uint32_t)tlow * 0x00010001u;
   const int ngx = (cw + 3) >> 2, nry = (ch + 1) >> 1;
   const int ntask = ngx * nry;
+  const int qcap = plan->fast_qcap;
   const float rngx = 1.0f / (float)ngx;
   int qn = 0;
   for (int base = 0; base < ntask; base += 64) {
@@ -446,25 +442,33 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Plan* __restrict__ plan
     while (flags) {
       const int b = __ffs(flags) - 1;
       flags &= flags - 1;
-      queue[qpos++] = (uint16_t)(((y + (b >> 2)) << 7) | (x + (b & 3)));
+      if (qpos < qcap) queue[qpos] = (uint16_t)(((y + (b >> 2)) << 7) | (x + (b & 3)));
+      ++qpos;
     }
     qn += __shfl(inc, 63, 64);
   }
   __syncthreads();
 
   // ---- 3. exact m for the survivors -------------------------------------------
-  for (int qi = lane; qi < qn; qi += 64) {
-    const int id = queue[qi];
-    const int x = id & 127, y = id >> 7;
+  // (a cell with more survivors than the queue holds - noise-like content - is scored
+  // and suppressed pixel by pixel instead)
+  const bool overflow = qn > qcap;
+  const float rcw = 1.0f / (float)cw;
+  const int nwork = overflow ? np : qn;
+  for (int qi = lane; qi < nwork; qi += 64) {
+    int x, y;
+    if (overflow) { y = (int)(((float)qi + 0.5f) * rcw); x = qi - y * cw; }
+    else { const int id = queue[qi]; x = id & 127; y = id >> 7; }
     mm[(y + 1) * TS + x + 4] = (uint8_t)fast_m<TS>(tile + (y + 3) * TS + x + 4);
   }
   __syncthreads();
 
   // ---- 4. suppression inside the cell, both thresholds -------------------------
   int anyIni = 0;
-  for (int qi = lane; qi < qn; qi += 64) {
-    const int id = queue[qi];
-    const int x = id & 127, y = id >> 7;
+  for (int qi = lane; qi < nwork; qi += 64) {
+    int x, y;
+    if (overflow) { y = (int)(((float)qi + 0.5f) * rcw); x = qi - y * cw; }
+    else { const int id = queue[qi]; x = id & 127; y = id >> 7; }
     const uint8_t* q = mm + (y + 1) * TS + x + 4;
     const int m = q[0];
     if (m > tlow) {
@@ -482,7 +486,6 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Plan* __restrict__ plan
 
   // ---- 5. ordered output ---------------------------------------------------------
   uint32_t* out = cand + (size_t)f * plan->cand_frame + L.cand_off + (size_t)cell * L.cand_cap_cell;
-  const float rcw = 1.0f / (float)cw;
   int running = 0;
   for (int wbase = 0; wbase < nwords; wbase += 64) {
     const int wi = wbase + lane;
