@@ -21,7 +21,8 @@ void launch_fast(const Plan& hp, const Plan* dp, const uint8_t* d_pyr, uint32_t*
                  int* d_cellCount, int f0, int nframes, hipStream_t s);
 void launch_octree(const Plan& hp, const Plan* dp, const uint32_t* d_cand, const int* d_cellCount,
                    uint32_t* d_flatA, uint32_t* d_flatB, uint32_t* d_sel, int* d_selCount,
-                   int f0, int nframes, hipStream_t s);
+                   uint8_t* d_workspace, int f0, int nframes, hipStream_t s);
+size_t octree_lds_bytes(const Plan& hp);
 void launch_assemble(const Plan& hp, const Plan* dp, const uint32_t* d_sel, const int* d_selCount,
                      int lap0, int lap1, float* d_kps, WorkItem* d_work, int* d_n, int* d_mono,
                      int f0, int nframes, hipStream_t s);
@@ -100,6 +101,7 @@ struct orbx_extractor {
   uint32_t* d_flatB = nullptr;
   uint32_t* d_sel = nullptr;
   int* d_selCount = nullptr;
+  uint8_t* d_octws = nullptr;  // quadtree node arrays when they do not fit LDS
   float* d_kps = nullptr;
   uint8_t* d_desc = nullptr;
   WorkItem* d_work = nullptr;
@@ -167,11 +169,11 @@ void orbx_extractor::freePlan() {
   (void)hipStreamSynchronize(stream);
   for (void* t : d_taps) (void)hipFree(t);
   d_taps.clear();
-  void* bufs[] = {dp, d_img, d_pyr, d_blur, d_cand, d_cellCount, d_flatA, d_flatB, d_sel, d_selCount,
+  void* bufs[] = {d_octws, dp, d_img, d_pyr, d_blur, d_cand, d_cellCount, d_flatA, d_flatB, d_sel, d_selCount,
                   d_kps, d_desc, d_work, d_n, d_mono};
   for (void* b : bufs) if (b) (void)hipFree(b);
   dp = nullptr; d_img = d_pyr = d_blur = d_desc = nullptr; d_cand = d_flatA = d_flatB = d_sel = nullptr;
-  d_cellCount = d_selCount = d_n = d_mono = nullptr; d_kps = nullptr; d_work = nullptr;
+  d_cellCount = d_selCount = d_n = d_mono = nullptr; d_octws = nullptr; d_kps = nullptr; d_work = nullptr;
   if (h_stage) (void)hipHostFree(h_stage);
   h_stage = nullptr; h_stage_bytes = 0;
   planned = false;
@@ -300,6 +302,11 @@ int orbx_extractor::ensurePlan(int W, int H) {
     const long fixed = (long)nodesCap * 86 + (long)(cellsMax + 1) * 4 + 64;
     const long keys = (32 * 1024 - fixed) / 8;
     hp.oct_keys_lds = keys < 256 ? 0 : (int)std::min(keys, 8192L);
+    hp.oct_ws_bytes = 0;
+    if (orbx::octree_lds_bytes(hp) > 96 * 1024) {
+      hp.oct_keys_lds = 0;
+      hp.oct_ws_bytes = (uint32_t)((orbx::octree_lds_bytes(hp) + 255) / 256 * 256);
+    }
   }
   maxKeypoints = selOff;
   pyr_bytes = pyrOff;
@@ -393,6 +400,7 @@ int orbx_extractor::ensurePlan(int W, int H) {
   HIP_TRY(hipMalloc((void**)&d_flatB, (size_t)B * hp.flat_frame * 4));
   HIP_TRY(hipMalloc((void**)&d_sel, (size_t)B * hp.sel_frame * 4));
   HIP_TRY(hipMalloc((void**)&d_selCount, (size_t)B * nl * 4));
+  if (hp.oct_ws_bytes) HIP_TRY(hipMalloc((void**)&d_octws, (size_t)B * nl * hp.oct_ws_bytes));
   HIP_TRY(hipMalloc((void**)&d_kps, (size_t)B * hp.kp_cap * 28));
   HIP_TRY(hipMalloc((void**)&d_desc, (size_t)B * hp.kp_cap * 32));
   HIP_TRY(hipMalloc((void**)&d_work, (size_t)B * hp.kp_cap * sizeof(WorkItem)));
@@ -416,7 +424,7 @@ int orbx_extractor::run(const uint8_t* d_images, int istride, size_t iframe, int
     HIP_TRY(hipEventRecord(ev[1], s));
     orbx::launch_fast(hp, dp, d_pyr, d_cand, d_cellCount, 0, nframes, s);
     HIP_TRY(hipEventRecord(ev[2], s));
-    orbx::launch_octree(hp, dp, d_cand, d_cellCount, d_flatA, d_flatB, d_sel, d_selCount, 0, nframes, s);
+    orbx::launch_octree(hp, dp, d_cand, d_cellCount, d_flatA, d_flatB, d_sel, d_selCount, d_octws, 0, nframes, s);
     HIP_TRY(hipEventRecord(ev[3], s));
     orbx::launch_assemble(hp, dp, d_sel, d_selCount, lap0, lap1, d_kps, d_work, d_n, d_mono, 0, nframes, s);
     HIP_TRY(hipEventRecord(ev[4], s));
@@ -434,7 +442,7 @@ int orbx_extractor::run(const uint8_t* d_images, int istride, size_t iframe, int
     HIP_TRY(hipStreamWaitEvent(q, evFork, 0));
     orbx::launch_blur(hp, dp, d_pyr, d_blur, 0, nframes, q);
     HIP_TRY(hipEventRecord(evJoin[0], q));
-    orbx::launch_octree(hp, dp, d_cand, d_cellCount, d_flatA, d_flatB, d_sel, d_selCount, 0, nframes, s);
+    orbx::launch_octree(hp, dp, d_cand, d_cellCount, d_flatA, d_flatB, d_sel, d_selCount, d_octws, 0, nframes, s);
     orbx::launch_assemble(hp, dp, d_sel, d_selCount, lap0, lap1, d_kps, d_work, d_n, d_mono, 0, nframes, s);
     HIP_TRY(hipStreamWaitEvent(s, evJoin[0], 0));
     orbx::launch_describe(hp, dp, d_pyr, d_blur, d_work, d_n, d_kps, d_desc, 0, nframes, s);

@@ -898,12 +898,17 @@ __global__ __launch_bounds__(64) void k_octree(const Plan* __restrict__ plan,
                                                uint32_t* __restrict__ flatA,
                                                uint32_t* __restrict__ flatB,
                                                uint32_t* __restrict__ sel,
-                                               int* __restrict__ selCount, int f0) {
-  extern __shared__ __align__(16) uint8_t smem[];
+                                               int* __restrict__ selCount,
+                                               uint8_t* __restrict__ workspace, int f0) {
+  extern __shared__ __align__(16) uint8_t smemDyn[];
   const int l = blockIdx.x, f = blockIdx.y + f0;
   const int lane = lane_id();
   const LevelDesc& L = plan->lv[l];
   const int cap = plan->oct_nodes_cap;
+  // node arrays live in LDS; plans whose arrays exceed it (tens of thousands of
+  // features per frame) use a per-(frame, level) slice of a global workspace instead
+  uint8_t* smem = plan->oct_ws_bytes ? workspace + ((size_t)f * plan->nlevels + l) * plan->oct_ws_bytes
+                                     : smemDyn;
   OctState st;
   st.cnt4 = (int4*)smem;                                    // 16-byte aligned first
   st.cur = (QNode*)(st.cnt4 + cap);
@@ -1475,10 +1480,11 @@ size_t octree_lds_bytes(const Plan& hp) {
 
 void launch_octree(const Plan& hp, const Plan* dp, const uint32_t* d_cand, const int* d_cellCount,
                    uint32_t* d_flatA, uint32_t* d_flatB, uint32_t* d_sel, int* d_selCount,
-                   int f0, int nframes, hipStream_t s) {
+                   uint8_t* d_workspace, int f0, int nframes, hipStream_t s) {
   dim3 grid(hp.nlevels, nframes);
-  hipLaunchKernelGGL(k_octree, grid, dim3(64), octree_lds_bytes(hp), s, dp, d_cand, d_cellCount,
-                     d_flatA, d_flatB, d_sel, d_selCount, f0);
+  const size_t lds = hp.oct_ws_bytes ? 0 : octree_lds_bytes(hp);
+  hipLaunchKernelGGL(k_octree, grid, dim3(64), lds, s, dp, d_cand, d_cellCount,
+                     d_flatA, d_flatB, d_sel, d_selCount, d_workspace, f0);
 }
 
 void launch_assemble(const Plan& hp, const Plan* dp, const uint32_t* d_sel, const int* d_selCount,
@@ -1511,6 +1517,7 @@ int launch_debug_sort(uint64_t* d_data, int n, hipStream_t s) {
 }
 
 int octree_set_lds_limit(const Plan& hp) {
+  if (hp.oct_ws_bytes) return 0;
   const size_t need = octree_lds_bytes(hp) + 256;
   if (need > 160 * 1024) return -1;
   if (need > 64 * 1024) {

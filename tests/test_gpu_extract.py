@@ -151,3 +151,46 @@ def test_device_sort_matches_std_sort(oracle):
         check(lib().orbx_debug_sort_records(0, ptr(rec), n))
         perm = (rec & np.uint64(0xFFFFFFFF)).astype(np.int32)
         assert np.array_equal(perm, perm_ref), (n, size[:8], ulx[:8])
+
+
+def test_4k_frame_10000_features(oracle):
+    """Config 5 shape: one synthetic 3840x2160 frame, 10000 features (the quadtree's node
+    arrays exceed LDS here and live in the global workspace)."""
+    img = orbx.textured_frame(77, 3840, 2160)
+    compare_full(oracle, img, (10000, 1.2, 8, 20, 7), (0, 0), check_stages=False)
+
+
+def test_many_features_small_image(oracle):
+    compare_full(oracle, adversarial("noise", 640, 480), (20000, 1.2, 6, 20, 7), (0, 0), check_stages=False)
+
+
+def test_batch_position_independence_and_idempotence():
+    """A frame's result does not depend on where it sits in a batch, on the batch size, or
+    on what the handle processed before (re-planning for another image size included)."""
+    ex = orbx.ORBextractor(1000, 1.2, 8, 20, 7, max_batch=64)
+    a = orbx.textured_frame(1, 752, 480)
+    b = orbx.textured_frame(2, 752, 480)
+    batch = np.stack([a, b] * 8 + [b, a] * 8)          # 32 frames
+    res = ex.extract_batch(batch, (0, 1000))
+    ex.extract_batch(np.stack([orbx.textured_frame(3, 512, 512)] * 3), (0, 0))   # other size in between
+    res2 = ex.extract_batch(batch[::-1].copy(), (0, 1000))[::-1]
+    single = ex(a, None, (0, 1000))
+    for r in (res, res2):
+        for f in range(32):
+            ref = res[0] if np.array_equal(batch[f], a) else res[1]
+            assert r[f][0] == ref[0]
+            assert np.array_equal(r[f][1], ref[1]) and np.array_equal(r[f][2], ref[2])
+    assert single[0] == res[0][0] and np.array_equal(single[1], res[0][1]) and np.array_equal(single[2], res[0][2])
+
+
+def test_device_resident_batch_matches_host_batch():
+    import torch
+    frames = np.stack([orbx.textured_frame(40 + i, 752, 480) for i in range(24)])
+    ex = orbx.ORBextractor(1000, 1.2, 8, 20, 7, max_batch=24)
+    host = ex.extract_batch(frames, (0, 1000))
+    d = torch.from_numpy(frames).cuda()
+    ex.extract_batch_device(d.data_ptr(), 24, 752, 480, 752, (0, 1000))
+    ex.sync()
+    for f in range(24):
+        mono, k, desc = ex.download(f)
+        assert mono == host[f][0] and np.array_equal(k, host[f][1]) and np.array_equal(desc, host[f][2])

@@ -135,3 +135,55 @@ def test_fisheye_config_knn_on_lapping_subsets(oracle):
     ridx, rdist = oracle.knn2(dl[ml:], dr[mr:])
     assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
     assert orbx.ratio_test(idx, dist).sum() > 50
+
+
+def test_knn2_large_properties():
+    """200k queries x 2M train rows (4e11 pairs; the oracle cannot run this): size-independent
+    properties - sharded == unsharded, planted rows found at distance 0 at their lowest index,
+    ordered neighbours, and a random sample checked against numpy brute force."""
+    import ctypes as C
+    import torch
+    from orb_slam3_amd._lib import lib, check
+    g = torch.Generator(device="cuda").manual_seed(5)
+    nq, nt = 200_000, 2_000_000
+    t = torch.randint(0, 256, (nt, 32), dtype=torch.uint8, device="cuda", generator=g)
+    q = torch.randint(0, 256, (nq, 32), dtype=torch.uint8, device="cuda", generator=g)
+    t[nt - 1000:] = t[:1000]                    # duplicates far apart: index tie-break across shards
+    src = torch.randint(0, nt, (nq // 10,), device="cuda", generator=g)
+    q[: nq // 10] = t[src]
+
+    def run(tt, off, oi, od):
+        check(lib().orbx_knn2_device(C.c_void_p(q.data_ptr()), nq, C.c_void_p(tt.data_ptr()), tt.shape[0], off,
+                                     C.c_void_p(oi.data_ptr()), C.c_void_p(od.data_ptr()), None))
+    idx = torch.empty((nq, 2), dtype=torch.int32, device="cuda")
+    dst = torch.empty((nq, 2), dtype=torch.int16, device="cuda")
+    run(t, 0, idx, dst)
+    shards = 8
+    b = orbx.shard_bounds(nt, shards)
+    pi = torch.empty((shards, nq, 2), dtype=torch.int32, device="cuda")
+    pd = torch.empty((shards, nq, 2), dtype=torch.int16, device="cuda")
+    for s in range(shards):
+        run(t[b[s]:b[s + 1]], b[s], pi[s], pd[s])
+    mi, md = torch.empty_like(idx), torch.empty_like(dst)
+    check(lib().orbx_top2_merge_device(C.c_void_p(pi.data_ptr()), C.c_void_p(pd.data_ptr()), shards, nq,
+                                       C.c_void_p(mi.data_ptr()), C.c_void_p(md.data_ptr()), None))
+    torch.cuda.synchronize()
+    assert torch.equal(mi, idx) and torch.equal(md, dst)
+    i_np = idx.cpu().numpy().view(np.uint32)
+    d_np = dst.cpu().numpy().view(np.uint16)
+    assert (d_np[:, 0] <= d_np[:, 1]).all() and (i_np[:, 0] != i_np[:, 1]).all()
+    assert (d_np[: nq // 10, 0] == 0).all()
+    src_np = src.cpu().numpy()
+    dup = src_np >= nt - 1000                   # planted from the duplicated tail -> earliest copy wins
+    want = np.where(dup, src_np - (nt - 1000), src_np)
+    hit = i_np[: nq // 10, 0]
+    # the planted row (or an identical earlier row) must be reported
+    assert (hit <= want).all()
+    assert (hit[~dup & (src_np >= 1000)] == want[~dup & (src_np >= 1000)]).mean() > 0.999
+    t_np = t.cpu().numpy()
+    q_np = q.cpu().numpy()
+    lut = np.array([bin(i).count("1") for i in range(256)], np.uint16)
+    for qi in np.random.default_rng(1).integers(0, nq, 24):
+        d = lut[np.bitwise_xor(t_np, q_np[qi])].sum(axis=1)
+        order = np.lexsort((np.arange(nt), d))[:2]
+        assert i_np[qi].tolist() == order.tolist() and d_np[qi].tolist() == d[order].tolist()
