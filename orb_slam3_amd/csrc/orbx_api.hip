@@ -392,7 +392,7 @@ int orbx_extractor::ensurePlan(int W, int H) {
   HIP_TRY(hipMalloc((void**)&dp, sizeof(Plan)));
   HIP_TRY(hipMemcpy(dp, &hp, sizeof(Plan), hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc((void**)&d_img, (size_t)B * W * H));
-  HIP_TRY(hipMalloc((void**)&d_pyr, pyrOff));
+  HIP_TRY(hipMalloc((void**)&d_pyr, pyrOff + 256));  // tile loads may overrun the last row by a few bytes
   HIP_TRY(hipMalloc((void**)&d_blur, blurOff + 256));  // window loads may overrun a row end by a few bytes
   HIP_TRY(hipMalloc((void**)&d_cand, (size_t)B * hp.cand_frame * 4));
   HIP_TRY(hipMalloc((void**)&d_cellCount, (size_t)B * hp.cells_per_frame * 4));

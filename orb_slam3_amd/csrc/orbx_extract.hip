@@ -379,15 +379,21 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Plan* __restrict__ plan
     const int shift = (X0 + 15) & 3;  // planes and rows are 64-byte aligned
     const uint8_t* g0 = pyr + L.pyr_off + (size_t)f * L.pyr_plane +
                         (size_t)(Y0 - 3 + ORBX_EDGE) * L.pstride + (X0 - 4 + ORBX_EDGE - shift);
-    const int nd = (cw + 10) >> 2;
-    const int total = (ch + 6) * nd;
-    const float rnd = 1.0f / (float)nd;
+    // one lane = 16 bytes of a tile row: a dword-aligned 16-byte load plus the next dword,
+    // shifted into place with v_alignbyte, one 16-byte LDS store
+    const int nq = TS / 16;
+    const int total = (ch + 6) * nq;
     for (int i = lane; i < total; i += 64) {
-      const int r = (int)(((float)i + 0.5f) * rnd);
-      const int n = i - r * nd;
-      const uint32_t* gp = (const uint32_t*)(g0 + (size_t)r * L.pstride) + n;
-      const uint32_t lo = gp[0], hi = gp[1];
-      *(uint32_t*)(tile + r * TS + 4 * n) = __builtin_amdgcn_alignbyte(hi, lo, shift);
+      const int r = i / nq, n = i - r * nq;
+      const uint8_t* gp = g0 + (size_t)r * L.pstride + 16 * n;
+      const U4A4 v = *(const U4A4*)gp;
+      const uint32_t v4 = *(const uint32_t*)(gp + 16);
+      uint4 o;
+      o.x = __builtin_amdgcn_alignbyte(v.y, v.x, shift);
+      o.y = __builtin_amdgcn_alignbyte(v.z, v.y, shift);
+      o.z = __builtin_amdgcn_alignbyte(v.w, v.z, shift);
+      o.w = __builtin_amdgcn_alignbyte(v4, v.w, shift);
+      *(uint4*)(tile + r * TS + 16 * n) = o;
     }
     const int mmq = ((ch + 2) * TS + 15) >> 4;
     for (int i = lane; i < mmq; i += 64) ((uint4*)mm)[i] = make_uint4(0, 0, 0, 0);
