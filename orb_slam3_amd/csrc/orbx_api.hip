@@ -18,10 +18,10 @@ namespace orbx {
 void launch_pyramid(const Plan& hp, const uint8_t* d_img, int istride, size_t iframe, uint8_t* d_pyr,
                     int f0, int nframes, hipStream_t s);
 void launch_fast(const Plan& hp, const Plan* dp, const uint8_t* d_pyr, uint32_t* d_cand,
-                 int* d_cellCount, int f0, int nframes, hipStream_t s);
+                 int* d_cellCount, int l0, int l1, int f0, int nframes, hipStream_t s);
 void launch_octree(const Plan& hp, const Plan* dp, const uint32_t* d_cand, const int* d_cellCount,
                    uint32_t* d_flatA, uint32_t* d_flatB, uint32_t* d_sel, int* d_selCount,
-                   uint8_t* d_workspace, int f0, int nframes, hipStream_t s);
+                   uint8_t* d_workspace, int l0, int l1, int f0, int nframes, hipStream_t s);
 size_t octree_lds_bytes(const Plan& hp);
 void launch_assemble(const Plan& hp, const Plan* dp, const uint32_t* d_sel, const int* d_selCount,
                      int lap0, int lap1, float* d_kps, WorkItem* d_work, int* d_n, int* d_mono,
@@ -422,9 +422,10 @@ int orbx_extractor::run(const uint8_t* d_images, int istride, size_t iframe, int
     HIP_TRY(hipEventRecord(ev[0], s));
     orbx::launch_pyramid(hp, d_images, istride, iframe, d_pyr, 0, nframes, s);
     HIP_TRY(hipEventRecord(ev[1], s));
-    orbx::launch_fast(hp, dp, d_pyr, d_cand, d_cellCount, 0, nframes, s);
+    orbx::launch_fast(hp, dp, d_pyr, d_cand, d_cellCount, 0, hp.nlevels, 0, nframes, s);
     HIP_TRY(hipEventRecord(ev[2], s));
-    orbx::launch_octree(hp, dp, d_cand, d_cellCount, d_flatA, d_flatB, d_sel, d_selCount, d_octws, 0, nframes, s);
+    orbx::launch_octree(hp, dp, d_cand, d_cellCount, d_flatA, d_flatB, d_sel, d_selCount, d_octws, 0,
+                        hp.nlevels, 0, nframes, s);
     HIP_TRY(hipEventRecord(ev[3], s));
     orbx::launch_assemble(hp, dp, d_sel, d_selCount, lap0, lap1, d_kps, d_work, d_n, d_mono, 0, nframes, s);
     HIP_TRY(hipEventRecord(ev[4], s));
@@ -433,16 +434,19 @@ int orbx_extractor::run(const uint8_t* d_images, int istride, size_t iframe, int
     orbx::launch_describe(hp, dp, d_pyr, d_blur, d_work, d_n, d_kps, d_desc, 0, nframes, s);
     HIP_TRY(hipEventRecord(ev[6], s));
   } else {
-    // The quadtree runs one wave per (frame, level) and leaves most of the chip idle;
-    // the blur only needs the pyramid, so it runs beside it on a second stream.
+    // The quadtree runs one wave per (frame, level), is latency-bound and leaves most of
+    // the chip idle; the blur only needs the pyramid, so it runs beside it on a second
+    // stream.  (Starting the big levels' quadtrees earlier, beside the detection of the
+    // small levels, measured slower: the two compete for LDS.)
     hipStream_t q = lane[0];
     orbx::launch_pyramid(hp, d_images, istride, iframe, d_pyr, 0, nframes, s);
-    orbx::launch_fast(hp, dp, d_pyr, d_cand, d_cellCount, 0, nframes, s);
+    orbx::launch_fast(hp, dp, d_pyr, d_cand, d_cellCount, 0, hp.nlevels, 0, nframes, s);
     HIP_TRY(hipEventRecord(evFork, s));
     HIP_TRY(hipStreamWaitEvent(q, evFork, 0));
     orbx::launch_blur(hp, dp, d_pyr, d_blur, 0, nframes, q);
     HIP_TRY(hipEventRecord(evJoin[0], q));
-    orbx::launch_octree(hp, dp, d_cand, d_cellCount, d_flatA, d_flatB, d_sel, d_selCount, d_octws, 0, nframes, s);
+    orbx::launch_octree(hp, dp, d_cand, d_cellCount, d_flatA, d_flatB, d_sel, d_selCount, d_octws, 0,
+                        hp.nlevels, 0, nframes, s);
     orbx::launch_assemble(hp, dp, d_sel, d_selCount, lap0, lap1, d_kps, d_work, d_n, d_mono, 0, nframes, s);
     HIP_TRY(hipStreamWaitEvent(s, evJoin[0], 0));
     orbx::launch_describe(hp, dp, d_pyr, d_blur, d_work, d_n, d_kps, d_desc, 0, nframes, s);

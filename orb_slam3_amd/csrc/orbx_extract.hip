@@ -352,11 +352,11 @@ template <int TS>
 __global__ __launch_bounds__(64) void k_fast_cells(const Plan* __restrict__ plan,
                                                    const uint8_t* __restrict__ pyr,
                                                    uint32_t* __restrict__ cand,
-                                                   int* __restrict__ cellCount, int f0) {
+                                                   int* __restrict__ cellCount, int f0, int cell0) {
   extern __shared__ __align__(16) uint8_t smem[];
   const int lane = threadIdx.x;
   const int f = blockIdx.y + f0;
-  const int cellg = blockIdx.x;
+  const int cellg = blockIdx.x + cell0;
   int l = 0;
   while (l + 1 < plan->nlevels && cellg >= plan->lv[l + 1].cell_first) ++l;
   const LevelDesc& L = plan->lv[l];
@@ -905,9 +905,9 @@ __global__ __launch_bounds__(64) void k_octree(const Plan* __restrict__ plan,
                                                uint32_t* __restrict__ flatB,
                                                uint32_t* __restrict__ sel,
                                                int* __restrict__ selCount,
-                                               uint8_t* __restrict__ workspace, int f0) {
+                                               uint8_t* __restrict__ workspace, int f0, int l0) {
   extern __shared__ __align__(16) uint8_t smemDyn[];
-  const int l = blockIdx.x, f = blockIdx.y + f0;
+  const int l = blockIdx.x + l0, f = blockIdx.y + f0;
   const int lane = lane_id();
   const LevelDesc& L = plan->lv[l];
   const int cap = plan->oct_nodes_cap;
@@ -1465,17 +1465,21 @@ size_t fast_lds_bytes(const Plan& hp, int ts) {
          (size_t)hp.fast_words * 8 + 16;
 }
 
+// cells of levels [l0, l1)
 void launch_fast(const Plan& hp, const Plan* dp, const uint8_t* d_pyr, uint32_t* d_cand,
-                 int* d_cellCount, int f0, int nframes, hipStream_t s) {
-  dim3 grid(hp.cells_per_frame, nframes);
+                 int* d_cellCount, int l0, int l1, int f0, int nframes, hipStream_t s) {
+  const int cell0 = hp.lv[l0].cell_first;
+  const int cell1 = l1 < hp.nlevels ? hp.lv[l1].cell_first : hp.cells_per_frame;
+  if (cell1 <= cell0) return;
+  dim3 grid(cell1 - cell0, nframes);
   const int ts = hp.fast_ts;
   const size_t lds = fast_lds_bytes(hp, ts);
   if (ts == 48)
-    hipLaunchKernelGGL(k_fast_cells<48>, grid, dim3(64), lds, s, dp, d_pyr, d_cand, d_cellCount, f0);
+    hipLaunchKernelGGL(k_fast_cells<48>, grid, dim3(64), lds, s, dp, d_pyr, d_cand, d_cellCount, f0, cell0);
   else if (ts == 64)
-    hipLaunchKernelGGL(k_fast_cells<64>, grid, dim3(64), lds, s, dp, d_pyr, d_cand, d_cellCount, f0);
+    hipLaunchKernelGGL(k_fast_cells<64>, grid, dim3(64), lds, s, dp, d_pyr, d_cand, d_cellCount, f0, cell0);
   else
-    hipLaunchKernelGGL(k_fast_cells<80>, grid, dim3(64), lds, s, dp, d_pyr, d_cand, d_cellCount, f0);
+    hipLaunchKernelGGL(k_fast_cells<80>, grid, dim3(64), lds, s, dp, d_pyr, d_cand, d_cellCount, f0, cell0);
 }
 
 size_t octree_lds_bytes(const Plan& hp) {
@@ -1486,11 +1490,12 @@ size_t octree_lds_bytes(const Plan& hp) {
 
 void launch_octree(const Plan& hp, const Plan* dp, const uint32_t* d_cand, const int* d_cellCount,
                    uint32_t* d_flatA, uint32_t* d_flatB, uint32_t* d_sel, int* d_selCount,
-                   uint8_t* d_workspace, int f0, int nframes, hipStream_t s) {
-  dim3 grid(hp.nlevels, nframes);
+                   uint8_t* d_workspace, int l0, int l1, int f0, int nframes, hipStream_t s) {
+  if (l1 <= l0) return;
+  dim3 grid(l1 - l0, nframes);
   const size_t lds = hp.oct_ws_bytes ? 0 : octree_lds_bytes(hp);
   hipLaunchKernelGGL(k_octree, grid, dim3(64), lds, s, dp, d_cand, d_cellCount,
-                     d_flatA, d_flatB, d_sel, d_selCount, d_workspace, f0);
+                     d_flatA, d_flatB, d_sel, d_selCount, d_workspace, f0, l0);
 }
 
 void launch_assemble(const Plan& hp, const Plan* dp, const uint32_t* d_sel, const int* d_selCount,
