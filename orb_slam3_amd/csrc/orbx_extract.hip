@@ -578,9 +578,15 @@ __device__ void oct_count(const OctState& st, int m) {
       const uint32_t* src = (((unsigned)nd.cnt >> 31) ? st.bufB : st.bufA) + nd.start;
       const int mx = nd.ulx + ((nd.brx - nd.ulx + 1) >> 1), my = nd.uly + ((nd.bry - nd.uly + 1) >> 1);
       int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-      for (int k = 0; k < cnt; ++k) {
-        const int q = quadrant_of(src[k], mx, my);
-        c0 += q == 0; c1 += q == 1; c2 += q == 2; c3 += q == 3;
+      for (int k = 0; k < cnt; k += 4) {   // 4 independent loads per trip; the tail re-reads key 0
+        uint32_t kk[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) kk[u] = src[k + u < cnt ? k + u : 0];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int q = k + u < cnt ? quadrant_of(kk[u], mx, my) : -1;
+          c0 += q == 0; c1 += q == 1; c2 += q == 2; c3 += q == 3;
+        }
       }
       st.cnt4[t] = make_int4(c0, c1, c2, c3);
     }
@@ -695,12 +701,19 @@ __device__ void oct_scatter(const OctState& st, int mEff) {
       const int mx = nd.ulx + ((nd.brx - nd.ulx + 1) >> 1), my = nd.uly + ((nd.bry - nd.uly + 1) >> 1);
       const int4 c = st.cnt4[t];
       int o0 = 0, o1 = c.x, o2 = c.x + c.y, o3 = c.x + c.y + c.z;
-      for (int k = 0; k < cnt; ++k) {
-        const uint32_t key = src[k];
-        const int q = quadrant_of(key, mx, my);
-        const int pos = q == 0 ? o0 : q == 1 ? o1 : q == 2 ? o2 : o3;
-        dst[pos] = key;
-        o0 += q == 0; o1 += q == 1; o2 += q == 2; o3 += q == 3;
+      for (int k = 0; k < cnt; k += 4) {
+        uint32_t kk[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) kk[u] = src[k + u < cnt ? k + u : 0];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (k + u < cnt) {
+            const int q = quadrant_of(kk[u], mx, my);
+            const int pos = q == 0 ? o0 : q == 1 ? o1 : q == 2 ? o2 : o3;
+            dst[pos] = kk[u];
+            o0 += q == 0; o1 += q == 1; o2 += q == 2; o3 += q == 3;
+          }
+        }
       }
       oct_write_children(st, nd, c, st.cbase[t], mx, my);
       st.cur[p].cnt = 0;
@@ -1091,9 +1104,13 @@ __global__ __launch_bounds__(64) void k_octree(const Plan* __restrict__ plan,
     const uint32_t* keys = (((unsigned)nd.cnt >> 31) ? st.bufB : st.bufA) + nd.start;
     const int cnt = qcount(nd);
     uint32_t best = keys[0];
-    for (int k = 1; k < cnt; ++k) {
-      const uint32_t key = keys[k];
-      if ((key >> 24) > (best >> 24)) best = key;
+    for (int k = 1; k < cnt; k += 4) {
+      uint32_t kk[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) kk[u] = keys[k + u < cnt ? k + u : 0];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (k + u < cnt && (kk[u] >> 24) > (best >> 24)) best = kk[u];
     }
     if (p < L.sel_cap) out[p] = best;
   }
