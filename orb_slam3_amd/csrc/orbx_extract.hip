@@ -66,6 +66,15 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 struct __attribute__((packed, aligned(4))) U4A4 { uint32_t x, y, z, w; };
 #define L0_ROWS 4  // rows per lane
 
+// Workgroups are handed to the 8 XCDs round-robin by linear id and every XCD has a private
+// L2.  For a 1-D launch of 8 * chunk workgroups this returns a work unit such that each XCD
+// walks one contiguous range of units, so neighbouring units (which share cache lines of the
+// image planes) meet in the same L2.  Units >= the real count must be skipped by the caller.
+__device__ __forceinline__ int xcd_contiguous_unit(int chunk) {
+  const int b = blockIdx.x;
+  return (b & 7) * chunk + (b >> 3);
+}
+
 __global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t* __restrict__ img, int W, int H,
                                                     int istride, size_t iframe,
                                                     uint8_t* __restrict__ dst, int pstride,
@@ -352,11 +361,15 @@ template <int TS>
 __global__ __launch_bounds__(64) void k_fast_cells(const Plan* __restrict__ plan,
                                                    const uint8_t* __restrict__ pyr,
                                                    uint32_t* __restrict__ cand,
-                                                   int* __restrict__ cellCount, int f0, int cell0) {
+                                                   int* __restrict__ cellCount, int f0, int cell0,
+                                                   int ncells, int nunits, int chunk) {
   extern __shared__ __align__(16) uint8_t smem[];
   const int lane = threadIdx.x;
-  const int f = blockIdx.y + f0;
-  const int cellg = blockIdx.x + cell0;
+  const int unit = xcd_contiguous_unit(chunk);
+  if (unit >= nunits) return;
+  const int fr = unit / ncells;
+  const int f = fr + f0;
+  const int cellg = unit - fr * ncells + cell0;
   int l = 0;
   while (l + 1 < plan->nlevels && cellg >= plan->lv[l + 1].cell_first) ++l;
   const LevelDesc& L = plan->lv[l];
@@ -1234,9 +1247,13 @@ __device__ __forceinline__ void blur_hrow(const uint8_t* rowp, uint32_t (&h)[4])
 
 __global__ __launch_bounds__(256) void k_blur(const Plan* __restrict__ plan,
                                               const uint8_t* __restrict__ pyr,
-                                              uint8_t* __restrict__ blur, int f0) {
-  const int f = blockIdx.y + f0;
-  const int tg = blockIdx.x;
+                                              uint8_t* __restrict__ blur, int f0, int ntiles,
+                                              int nunits, int chunk) {
+  const int unit = xcd_contiguous_unit(chunk);
+  if (unit >= nunits) return;
+  const int fr = unit / ntiles;
+  const int f = fr + f0;
+  const int tg = unit - fr * ntiles;
   int l = 0;
   while (l + 1 < plan->nlevels && tg >= plan->lv[l + 1].tile_first) ++l;
   const LevelDesc& L = plan->lv[l];
@@ -1340,12 +1357,16 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Plan* __restrict_
                                                          const WorkItem* __restrict__ work,
                                                          const int* __restrict__ nOut,
                                                          float* __restrict__ kps,
-                                                         uint8_t* __restrict__ desc, int f0) {
-  const int f = blockIdx.y + f0;
+                                                         uint8_t* __restrict__ desc, int f0,
+                                                         int nblk, int nunits, int chunk) {
+  const int unit = xcd_contiguous_unit(chunk);
+  if (unit >= nunits) return;
+  const int fr = unit / nblk;
+  const int f = fr + f0;
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, j16 = lane & 15;
   const int n = nOut[f];
-  const int kbase = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+  const int kbase = ((unit - fr * nblk) * 4 + (threadIdx.x >> 6)) * 4;
   if (kbase >= n) return;
   const int k = kbase + g;
   const bool valid = k < n;
@@ -1488,15 +1509,19 @@ void launch_fast(const Plan& hp, const Plan* dp, const uint8_t* d_pyr, uint32_t*
   const int cell0 = hp.lv[l0].cell_first;
   const int cell1 = l1 < hp.nlevels ? hp.lv[l1].cell_first : hp.cells_per_frame;
   if (cell1 <= cell0) return;
-  dim3 grid(cell1 - cell0, nframes);
+  const int ncells = cell1 - cell0, nunits = ncells * nframes, chunk = (nunits + 7) / 8;
+  dim3 grid(8 * chunk);
   const int ts = hp.fast_ts;
   const size_t lds = fast_lds_bytes(hp, ts);
   if (ts == 48)
-    hipLaunchKernelGGL(k_fast_cells<48>, grid, dim3(64), lds, s, dp, d_pyr, d_cand, d_cellCount, f0, cell0);
+    hipLaunchKernelGGL(k_fast_cells<48>, grid, dim3(64), lds, s, dp, d_pyr, d_cand, d_cellCount, f0, cell0,
+                       ncells, nunits, chunk);
   else if (ts == 64)
-    hipLaunchKernelGGL(k_fast_cells<64>, grid, dim3(64), lds, s, dp, d_pyr, d_cand, d_cellCount, f0, cell0);
+    hipLaunchKernelGGL(k_fast_cells<64>, grid, dim3(64), lds, s, dp, d_pyr, d_cand, d_cellCount, f0, cell0,
+                       ncells, nunits, chunk);
   else
-    hipLaunchKernelGGL(k_fast_cells<80>, grid, dim3(64), lds, s, dp, d_pyr, d_cand, d_cellCount, f0, cell0);
+    hipLaunchKernelGGL(k_fast_cells<80>, grid, dim3(64), lds, s, dp, d_pyr, d_cand, d_cellCount, f0, cell0,
+                       ncells, nunits, chunk);
 }
 
 size_t octree_lds_bytes(const Plan& hp) {
@@ -1525,16 +1550,17 @@ void launch_assemble(const Plan& hp, const Plan* dp, const uint32_t* d_sel, cons
 
 void launch_blur(const Plan& hp, const Plan* dp, const uint8_t* d_pyr, uint8_t* d_blur, int f0,
                  int nframes, hipStream_t s) {
-  dim3 grid(hp.tiles_per_frame, nframes);
-  hipLaunchKernelGGL(k_blur, grid, dim3(256), 0, s, dp, d_pyr, d_blur, f0);
+  const int nunits = hp.tiles_per_frame * nframes, chunk = (nunits + 7) / 8;
+  hipLaunchKernelGGL(k_blur, dim3(8 * chunk), dim3(256), 0, s, dp, d_pyr, d_blur, f0,
+                     hp.tiles_per_frame, nunits, chunk);
 }
 
 void launch_describe(const Plan& hp, const Plan* dp, const uint8_t* d_pyr, const uint8_t* d_blur,
                      const WorkItem* d_work, const int* d_n, float* d_kps, uint8_t* d_desc,
                      int f0, int nframes, hipStream_t s) {
-  dim3 grid((hp.kp_cap + 15) / 16, nframes);
-  hipLaunchKernelGGL(k_orient_describe, grid, dim3(256), 0, s, dp, d_pyr, d_blur, d_work, d_n, d_kps,
-                     d_desc, f0);
+  const int nblk = (hp.kp_cap + 15) / 16, nunits = nblk * nframes, chunk = (nunits + 7) / 8;
+  hipLaunchKernelGGL(k_orient_describe, dim3(8 * chunk), dim3(256), 0, s, dp, d_pyr, d_blur, d_work,
+                     d_n, d_kps, d_desc, f0, nblk, nunits, chunk);
 }
 
 int launch_debug_sort(uint64_t* d_data, int n, hipStream_t s) {

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Condenses rocprofv3 output directories (kernel trace + counter passes written by
+tools/collect_profiles.sh) into small per-kernel tables: <out>/<tag>_kernel_stats.csv
+(copied from the trace) and <out>/<tag>_pmc_summary.json (mean counter value per launch of
+each kernel).  FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB; on gfx950
+FETCH_SIZE tallies the 128-byte requests of wide coalesced reads at 64 bytes, so the
+summary lists both the raw value and the doubled one."""
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import sys
+
+
+def short(name):
+    name = re.sub(r"\(.*$", "", name)
+    name = name.replace("orbx::", "").replace("(anonymous namespace)::", "")
+    return name.replace("void ", "").strip()
+
+
+def main():
+    out, tag = sys.argv[1], sys.argv[2]
+    for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
+        shutil.copy(f, os.path.join(out, "%s_kernel_stats.csv" % tag))
+    summ = {}
+    for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
+        for f in glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True):
+            with open(f, newline="") as fh:
+                for row in csv.DictReader(fh):
+                    k = short(row["Kernel_Name"])
+                    if not k.startswith("k_"):
+                        continue
+                    e = summ.setdefault(k, {}).setdefault(row["Counter_Name"], [0.0, 0])
+                    e[0] += float(row["Counter_Value"])
+                    e[1] += 1
+    res = {}
+    for k, cs in sorted(summ.items()):
+        r = {c: v[0] / v[1] for c, v in cs.items()}
+        r["launches_sampled"] = max(v[1] for v in cs.values())
+        if "FETCH_SIZE" in r:
+            r["hbm_read_bytes_raw"] = r["FETCH_SIZE"] * 1024
+            r["hbm_read_bytes_x2"] = r["FETCH_SIZE"] * 2048
+        if "WRITE_SIZE" in r:
+            r["hbm_write_bytes"] = r["WRITE_SIZE"] * 1024
+        if "SQ_ACTIVE_INST_VALU" in r and r.get("SQ_BUSY_CYCLES"):
+            # 4 SIMDs per CU each issue VALU independently; ACTIVE_INST_VALU is in quad-cycles
+            r["valu_per_wave"] = r["SQ_INSTS_VALU"] / max(r.get("SQ_WAVES", 1), 1)
+        res[k] = r
+    with open(os.path.join(out, "%s_pmc_summary.json" % tag), "w") as fh:
+        json.dump(res, fh, indent=1, sort_keys=True)
+    for k, r in res.items():
+        print(k, {a: (round(b, 1) if isinstance(b, float) else b) for a, b in r.items()})
+
+
+if __name__ == "__main__":
+    main()
