@@ -49,6 +49,30 @@ def algorithmic_bytes(w, h, nlevels, scale_factor, nkp):
     return stage, total
 
 
+KERNEL_OF_STAGE = {"fast": "k_fast_cells", "blur": "k_blur", "pyramid": "k_pyr_"}
+
+
+def pmc_traffic(stage, batch):
+    """HBM-side bytes per launch of the stage's kernel(s) from the committed rocprofv3 counter
+    passes of this same command (FETCH_SIZE and WRITE_SIZE are collected in separate runs and
+    cannot be read from inside the process).  FETCH_SIZE is in KiB and, on gfx950, tallies the
+    128-byte requests of wide coalesced reads at 64 bytes, hence the factor 2; WRITE_SIZE KiB is
+    exact.  Returns None when no summary for this batch size is present."""
+    path = os.path.join(ROOT, "profiles", "r1_final_bench_b%d_pmc_summary.json" % batch)
+    if not os.path.exists(path):
+        return None, None
+    with open(path) as fh:
+        summ = json.load(fh)
+    total, launches = 0.0, 0
+    for name, r in summ.items():
+        if name.startswith(KERNEL_OF_STAGE[stage]) and "FETCH_SIZE" in r and "WRITE_SIZE" in r:
+            per = r["FETCH_SIZE"] * 2048.0 + r["WRITE_SIZE"] * 1024.0
+            n = PARAMS[2] - 1 if name.startswith("k_pyr_resize") else 1   # launches per step
+            total += per * n
+            launches += n
+    return (total if launches else None), os.path.relpath(path, ROOT)
+
+
 def cpu_baseline(frames, seconds_budget=15.0):
     """The CPU oracle (a restatement of the reference extractor; the reference itself needs
     OpenCV and cannot be built here) on this host's cores, one extractor per thread,
@@ -199,6 +223,7 @@ def main():
         # dominant bandwidth-bound kernel = slowest of the stages that have an HBM roofline
         dom = max(stage_bytes, key=lambda k: acc[k])
         achieved = stage_bytes[dom] * B / (acc[dom] * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(dom, B)
         out = {
             "metric": "ORB frames/s @752x480,1000kp,8lvl",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -210,7 +235,9 @@ def main():
                                    "resident in HBM", "frames_per_step_per_gpu": B,
                        "keypoints_per_frame": nkp, "parallelism": "frames sharded, no collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": stage_bytes[dom] * B,
                          "algorithmic_bytes_per_frame": stage_bytes[dom]},
             "stage_ms_per_step": acc,
             "whole_frame_roofline_frac": fps / world * frame_bytes / (HBM_PEAK_GBS * 1e9),

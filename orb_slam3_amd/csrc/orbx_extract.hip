@@ -933,7 +933,9 @@ __global__ __launch_bounds__(64) void k_octree(const Plan* __restrict__ plan,
                                                int* __restrict__ selCount,
                                                uint8_t* __restrict__ workspace, int f0, int l0) {
   extern __shared__ __align__(16) uint8_t smemDyn[];
-  const int l = blockIdx.x + l0, f = blockIdx.y + f0;
+  // rotate the level with the frame: workgroups go to the 8 XCDs round-robin, and a fixed
+  // level per XCD would leave the XCD that holds level 0 with more than twice the work
+  const int l = (int)((blockIdx.x + blockIdx.y) % gridDim.x) + l0, f = blockIdx.y + f0;
   const int lane = lane_id();
   const LevelDesc& L = plan->lv[l];
   const int cap = plan->oct_nodes_cap;
