@@ -183,6 +183,34 @@ int orbx_stereo_band_match(int device_id, const orbx_keypoint* kps_l, const uint
                            const float* scale_factors, int nlevels, int n_rows, float min_d,
                            float max_d, int32_t* best_idx, int32_t* best_dist);
 
+/* ---- stereo association on device-resident extractions --------------------- */
+/* Frame::ComputeStereoMatches, core/src/Frame.cc:831-996, for frames
+ * [0, n_frames) of the last batched (or single-frame) calls on `left` and
+ * `right` (same device, image size, nlevels and scale factor): row-band
+ * descriptor search (:840-908), 11x11 L1 search over +-5 columns on pyramid
+ * level kpL.octave of both handles with parabola refinement (:910-981),
+ * disparity/depth, and removal of matches whose L1 distance is >= 1.5*1.4*
+ * median (:984-995).  mbf and mb are Frame::mbf and Frame::mb.  The pyramids,
+ * keypoints and descriptors are read where the extractions left them in
+ * device memory.  Asynchronous on left's stream (ordered after right's
+ * stream); results stay in left's device buffers.  Keypoints whose windows
+ * would leave the level image (a cv::Exception in the reference) get no
+ * match. */
+int orbx_stereo_match_batch_device(orbx_extractor* left, orbx_extractor* right, int n_frames,
+                                   float mbf, float mb);
+/* mvuRight / mvDepth of the last stereo call: float [n_frames][cap], entry i
+ * belongs to left keypoint i, -1 = no match (Frame.cc:832-833). */
+int orbx_stereo_results_device(orbx_extractor* left, float** d_uright, float** d_depth, int* cap);
+/* Copy frame f to the host (waits for the stereo call).  l1_dist (may be
+ * NULL) receives the winning L1 distance of every keypoint that reached
+ * Frame.cc:979, before the median rule, else -1. */
+int orbx_stereo_download(orbx_extractor* left, int frame, float* uright, float* depth,
+                         int32_t* l1_dist, int cap, int* n_out);
+/* Single stereo frame after orbx_extract on both handles: the drop-in for
+ * Frame::ComputeStereoMatches.  uright / depth hold cap floats. */
+int orbx_stereo_match(orbx_extractor* left, orbx_extractor* right, float mbf, float mb,
+                      float* uright, float* depth, int cap, int* n_out);
+
 /* ---- synthetic input ------------------------------------------------------- */
 /* Deterministic textured test frame (PCG32-seeded rectangles + noise + 3x3
  * box blur), written to dst (height rows of stride bytes).  Host only. */

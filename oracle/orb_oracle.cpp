@@ -797,4 +797,91 @@ void orc_stereo_band_match(const void* kpsL28, const uint8_t* descL, int nL, con
   }
 }
 
+// Frame::ComputeStereoMatches, core/src/Frame.cc:831-996: row-band descriptor search, 11x11 L1
+// refinement over +-5 columns on pyramid level kpL.octave of both cameras, parabola fit,
+// disparity/depth, then removal of matches whose L1 distance is >= 1.5*1.4*median.
+// hl / hr hold the pyramids of the last orc_extract calls on the left / right image; the
+// keypoints and descriptors are those calls' outputs.  uRight / depth hold nL floats (-1 = no
+// match, :832-833); sadDist (optional) receives the winning L1 distance of every keypoint that
+// reached :979, else -1.  Where the reference would index outside a level image (cv::Mat
+// rowRange / colRange raise cv::Exception) or outside the row table, the keypoint is skipped.
+int orc_stereo_match(orc_extractor* hl, orc_extractor* hr, const void* kpsL28, const uint8_t* descL,
+                     int nL, const void* kpsR28, const uint8_t* descR, int nR, float mbf, float mb,
+                     float* uRight, float* depth, int* sadDist) {
+  Extractor* eL = reinterpret_cast<Extractor*>(hl);
+  Extractor* eR = reinterpret_cast<Extractor*>(hr);
+  if (eL->pyr.empty() || eR->pyr.size() != eL->pyr.size()) return -1;
+  const KeyPoint* L = (const KeyPoint*)kpsL28;
+  const KeyPoint* R = (const KeyPoint*)kpsR28;
+  for (int i = 0; i < nL; ++i) { uRight[i] = -1.0f; depth[i] = -1.0f; if (sadDist) sadDist[i] = -1; }
+  const int thOrbDist = (100 + 50) / 2;                     // :835
+  const int nRows = eL->pyr[0].h;                           // :837
+  const float minZ = mb, minD = 0, maxD = mbf / minZ;       // :859-861
+  std::vector<int> bestIdx(nL), bestDistV(nL);
+  orc_stereo_band_match(kpsL28, descL, nL, kpsR28, descR, nR, eL->scale.data(), nRows, minD, maxD,
+                        bestIdx.data(), bestDistV.data());  // :840-908
+  std::vector<std::pair<int, int>> vDistIdx;
+  for (int iL = 0; iL < nL; ++iL) {
+    if (!(bestDistV[iL] < thOrbDist)) continue;             // :911
+    const KeyPoint& kpL = L[iL];
+    const float uL = kpL.x;
+    const float uR0 = R[bestIdx[iL]].x;
+    const float scaleFactor = eL->invScale[kpL.octave];
+    const float scaleduL = std::round(kpL.x * scaleFactor);
+    const float scaledvL = std::round(kpL.y * scaleFactor);
+    const float scaleduR0 = std::round(uR0 * scaleFactor);
+    const int w = 5, Lw = 5;
+    const Plane& PL = eL->pyr[kpL.octave];
+    const Plane& PR = eR->pyr[kpL.octave];
+    const float iniu = scaleduR0 + Lw - w;
+    const float endu = scaleduR0 + Lw + w + 1;
+    const int cu = (int)scaleduL, cv = (int)scaledvL, cr = (int)scaleduR0;
+    // left window inside the left level (rowRange/colRange preconditions, :921-923)
+    if (cv - w < 0 || cv + w + 1 > PL.h || cu - w < 0 || cu + w + 1 > PL.w) continue;
+    if (iniu < 0 || endu >= PR.w) continue;                 // :933-935
+    if (cv + w + 1 > PR.h || cr - Lw - w < 0) continue;     // right windows inside the right level
+    int bestDist = INT_MAX, bestincR = 0;
+    float vDists[2 * 5 + 1];
+    for (int incR = -Lw; incR <= Lw; ++incR) {
+      int sum = 0;                                          // cv::norm(IL, IR, NORM_L1), :943
+      for (int dy = -w; dy <= w; ++dy) {
+        const uint8_t* a = PL.roi() + (size_t)(cv + dy) * PL.stride + cu;
+        const uint8_t* b = PR.roi() + (size_t)(cv + dy) * PR.stride + cr + incR;
+        for (int dx = -w; dx <= w; ++dx) sum += std::abs((int)a[dx] - (int)b[dx]);
+      }
+      const float dist = (float)(double)sum;
+      if (dist < bestDist) { bestDist = (int)dist; bestincR = incR; }
+      vDists[Lw + incR] = dist;
+    }
+    if (bestincR == -Lw || bestincR == Lw) continue;        // :952-953
+    const float dist1 = vDists[Lw + bestincR - 1];
+    const float dist2 = vDists[Lw + bestincR];
+    const float dist3 = vDists[Lw + bestincR + 1];
+    const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+    if (deltaR < -1 || deltaR > 1) continue;
+    float bestuR = eL->scale[kpL.octave] * ((float)scaleduR0 + (float)bestincR + deltaR);
+    float disparity = (uL - bestuR);
+    if (disparity >= minD && disparity < maxD) {
+      if (disparity <= 0) {
+        disparity = 0.01;
+        bestuR = uL - 0.01;
+      }
+      depth[iL] = mbf / disparity;
+      uRight[iL] = bestuR;
+      if (sadDist) sadDist[iL] = bestDist;
+      vDistIdx.push_back(std::make_pair(bestDist, iL));
+    }
+  }
+  if (vDistIdx.empty()) return 0;                           // reference: undefined (reads [0])
+  std::sort(vDistIdx.begin(), vDistIdx.end());              // :984
+  const float median = vDistIdx[vDistIdx.size() / 2].first;
+  const float thDist = 1.5f * 1.4f * median;
+  for (int i = (int)vDistIdx.size() - 1; i >= 0; --i) {
+    if (vDistIdx[i].first < thDist) break;
+    uRight[vDistIdx[i].second] = -1;
+    depth[vDistIdx[i].second] = -1;
+  }
+  return 0;
+}
+
 }  // extern "C"

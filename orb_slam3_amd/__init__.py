@@ -4,11 +4,13 @@ Host-side mirror of the reference's interface for this path:
   ORBextractor              core/lib/ORB/extractor.h:45-102
   descriptor_distance       ORBmatcher::DescriptorDistance, core/lib/ORB/matcher.h:42
   knn_match2 / stereo_band_match   the matching loops of core/src/Frame.cc:1177, 840-908
+  compute_stereo_matches    Frame::ComputeStereoMatches, core/src/Frame.cc:831-996
 All compute runs in liborbx_hip.so (hand-written gfx950 kernels behind the C
 ABI of include/orbx.h); this package only marshals arguments.
 """
 from ._lib import KEYPOINT_DTYPE, OrbxError, lib  # noqa: F401
 from .extractor import ORBextractor  # noqa: F401
 from .matcher import (descriptor_distance, knn_match2, ratio_test, stereo_band_match,  # noqa: F401
-                      knn_match2_sharded, shard_bounds)
+                      knn_match2_sharded, shard_bounds, compute_stereo_matches,
+                      compute_stereo_matches_batch, stereo_download)
 from .synth import textured_frame  # noqa: F401

@@ -79,6 +79,10 @@ SIGNATURES = {
     "orbx_top2_merge_device": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),
     "orbx_stereo_band_match": (C.c_int, [C.c_int, _P, _P, C.c_int, _P, _P, C.c_int, _f32p, C.c_int,
                                          C.c_int, C.c_float, C.c_float, _P, _P]),
+    "orbx_stereo_match_batch_device": (C.c_int, [_P, _P, C.c_int, C.c_float, C.c_float]),
+    "orbx_stereo_results_device": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), _i32p]),
+    "orbx_stereo_download": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int, _i32p]),
+    "orbx_stereo_match": (C.c_int, [_P, _P, C.c_float, C.c_float, _P, _P, C.c_int, _i32p]),
     "orbx_synth_frame": (C.c_int, [C.c_uint32, C.c_int, C.c_int, C.c_int, _P]),
 }
 

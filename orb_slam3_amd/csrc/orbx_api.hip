@@ -32,6 +32,11 @@ void launch_describe(const Plan& hp, const Plan* dp, const uint8_t* d_pyr, const
                      const WorkItem* d_work, const int* d_n, float* d_kps, uint8_t* d_desc,
                      int f0, int nframes, hipStream_t s);
 int octree_set_lds_limit(const Plan& hp);
+void launch_stereo(const Plan& hp, const Plan* dp, const uint8_t* pyrL, const uint8_t* pyrR,
+                   const float* kpsL, const uint8_t* descL, const int* nL, int capL,
+                   const float* kpsR, const uint8_t* descR, const int* nR, int capR, float mbf,
+                   float mb, int* bandIdx, int* bandDist, int* sadDist, float* uRight, float* depth,
+                   int nframes, hipStream_t s);
 int launch_debug_sort(uint64_t* d_data, int n, hipStream_t s);
 }  // namespace orbx
 
@@ -108,6 +113,14 @@ struct orbx_extractor {
   int* d_n = nullptr;
   int* d_mono = nullptr;
   size_t pyr_bytes = 0;
+  // stereo association results of this (left) handle, allocated by the first stereo call
+  int* d_stBandIdx = nullptr;
+  int* d_stBandDist = nullptr;
+  int* d_stSad = nullptr;
+  float* d_stURight = nullptr;
+  float* d_stDepth = nullptr;
+  int stereoFrames = 0;
+  hipEvent_t evStereo = nullptr;
 
   // pinned host staging
   uint8_t* h_stage = nullptr;
@@ -169,6 +182,9 @@ void orbx_extractor::freePlan() {
   (void)hipStreamSynchronize(stream);
   for (void* t : d_taps) (void)hipFree(t);
   d_taps.clear();
+  void* sbufs[] = {d_stBandIdx, d_stBandDist, d_stSad, d_stURight, d_stDepth};
+  for (void* b : sbufs) if (b) (void)hipFree(b);
+  d_stBandIdx = d_stBandDist = d_stSad = nullptr; d_stURight = d_stDepth = nullptr; stereoFrames = 0;
   void* bufs[] = {d_octws, dp, d_img, d_pyr, d_blur, d_cand, d_cellCount, d_flatA, d_flatB, d_sel, d_selCount,
                   d_kps, d_desc, d_work, d_n, d_mono};
   for (void* b : bufs) if (b) (void)hipFree(b);
@@ -516,6 +532,7 @@ void orbx_destroy(orbx_extractor* ex) {
     if (ex->evJoin[k]) (void)hipEventDestroy(ex->evJoin[k]);
   }
   if (ex->evFork) (void)hipEventDestroy(ex->evFork);
+  if (ex->evStereo) (void)hipEventDestroy(ex->evStereo);
   if (ex->stream) (void)hipStreamDestroy(ex->stream);
   delete ex;
 }
@@ -646,6 +663,84 @@ int orbx_extract(orbx_extractor* ex, const uint8_t* img, int width, int height, 
   if (n_out) *n_out = n;
   if (mono_out) *mono_out = mono;
   return st;
+}
+
+// ---- stereo association on two device-resident extractions ---------------------------------
+static bool same_geometry(const orbx_extractor* a, const orbx_extractor* b) {
+  return a->planned && b->planned && a->device == b->device && a->hp.W == b->hp.W &&
+         a->hp.H == b->hp.H && a->prm.nlevels == b->prm.nlevels &&
+         a->prm.scale_factor == b->prm.scale_factor;
+}
+
+int orbx_stereo_match_batch_device(orbx_extractor* left, orbx_extractor* right, int n_frames, float mbf,
+                                   float mb) {
+  if (!left || !right || left == right || n_frames <= 0 || !(mb > 0.f) || !(mbf > 0.f))
+    return ORBX_ERR_BAD_ARG;
+  if (!same_geometry(left, right)) return ORBX_ERR_BAD_ARG;
+  if (n_frames > left->lastFrames || n_frames > right->lastFrames) return ORBX_ERR_BATCH;
+  orbx_extractor* ex = left;
+  if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  auto& last_hip_error = ex->last_hip_error;
+  if (!ex->d_stURight) {
+    const size_t slots = (size_t)ex->prm.max_batch * ex->hp.kp_cap;
+    HIP_TRY(hipMalloc((void**)&ex->d_stBandIdx, slots * 4));
+    HIP_TRY(hipMalloc((void**)&ex->d_stBandDist, slots * 4));
+    HIP_TRY(hipMalloc((void**)&ex->d_stSad, slots * 4));
+    HIP_TRY(hipMalloc((void**)&ex->d_stURight, slots * 4));
+    HIP_TRY(hipMalloc((void**)&ex->d_stDepth, slots * 4));
+  }
+  if (!ex->evStereo) HIP_TRY(hipEventCreateWithFlags(&ex->evStereo, hipEventDisableTiming));
+  // the right extraction runs on its own stream: order this work after it
+  HIP_TRY(hipEventRecord(ex->evStereo, right->stream));
+  HIP_TRY(hipStreamWaitEvent(ex->stream, ex->evStereo, 0));
+  orbx::launch_stereo(ex->hp, ex->dp, ex->d_pyr, right->d_pyr, ex->d_kps, ex->d_desc, ex->d_n,
+                      ex->hp.kp_cap, right->d_kps, right->d_desc, right->d_n, right->hp.kp_cap, mbf, mb,
+                      ex->d_stBandIdx, ex->d_stBandDist, ex->d_stSad, ex->d_stURight, ex->d_stDepth,
+                      n_frames, ex->stream);
+  HIP_TRY(hipGetLastError());
+  // the right handle's buffers must not be overwritten before this work has read them
+  HIP_TRY(hipEventRecord(ex->evStereo, ex->stream));
+  HIP_TRY(hipStreamWaitEvent(right->stream, ex->evStereo, 0));
+  ex->stereoFrames = n_frames;
+  return ORBX_OK;
+}
+
+int orbx_stereo_results_device(orbx_extractor* left, float** d_uright, float** d_depth, int* cap) {
+  if (!left || !left->planned || !left->d_stURight) return ORBX_ERR_BAD_ARG;
+  if (d_uright) *d_uright = left->d_stURight;
+  if (d_depth) *d_depth = left->d_stDepth;
+  if (cap) *cap = left->hp.kp_cap;
+  return ORBX_OK;
+}
+
+int orbx_stereo_download(orbx_extractor* left, int frame, float* uright, float* depth,
+                         int32_t* l1_dist, int cap, int* n_out) {
+  orbx_extractor* ex = left;
+  if (!ex || !ex->planned || !ex->d_stURight || frame < 0 || frame >= ex->stereoFrames)
+    return ORBX_ERR_BAD_ARG;
+  if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  auto& last_hip_error = ex->last_hip_error;
+  hipStream_t s = ex->stream;
+  int n = 0;
+  HIP_TRY(hipMemcpyAsync(&n, ex->d_n + frame, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (n_out) *n_out = n;
+  if (n > cap) return ORBX_ERR_CAPACITY;
+  if (n > 0) {
+    const size_t base = (size_t)frame * ex->hp.kp_cap;
+    if (uright) HIP_TRY(hipMemcpyAsync(uright, ex->d_stURight + base, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    if (depth) HIP_TRY(hipMemcpyAsync(depth, ex->d_stDepth + base, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    if (l1_dist) HIP_TRY(hipMemcpyAsync(l1_dist, ex->d_stSad + base, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
+  return ORBX_OK;
+}
+
+int orbx_stereo_match(orbx_extractor* left, orbx_extractor* right, float mbf, float mb, float* uright,
+                      float* depth, int cap, int* n_out) {
+  int st = orbx_stereo_match_batch_device(left, right, 1, mbf, mb);
+  if (st != ORBX_OK) return st;
+  return orbx_stereo_download(left, 0, uright, depth, nullptr, cap, n_out);
 }
 
 int orbx_level_dims(orbx_extractor* ex, int level, int* width, int* height, int* stride) {

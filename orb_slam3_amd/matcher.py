@@ -57,6 +57,39 @@ def stereo_band_match(kps_l, desc_l, kps_r, desc_r, scale_factors, n_rows, min_d
     return bi, bd
 
 
+def compute_stereo_matches_batch(ex_left, ex_right, n_frames, mbf, mb):
+    """Frame::ComputeStereoMatches (core/src/Frame.cc:831-996) for frames [0, n_frames) of the
+    last batched extractions on the two ORBextractor handles; everything stays on the device.
+    Asynchronous; fetch results with stereo_download()."""
+    check(lib().orbx_stereo_match_batch_device(ex_left._h, ex_right._h, int(n_frames), float(mbf),
+                                               float(mb)), "orbx_stereo_match_batch_device")
+
+
+def stereo_download(ex_left, frame, with_l1=False):
+    """(mvuRight, mvDepth[, L1 distance]) of one frame of the last stereo call."""
+    cap = ex_left.max_keypoints()
+    ur = np.empty(cap, np.float32)
+    dp = np.empty(cap, np.float32)
+    l1 = np.empty(cap, np.int32) if with_l1 else None
+    n = C.c_int32()
+    check(lib().orbx_stereo_download(ex_left._h, int(frame), ptr(ur), ptr(dp), ptr(l1), cap, C.byref(n)),
+          "orbx_stereo_download")
+    out = (ur[:n.value].copy(), dp[:n.value].copy())
+    return out + (l1[:n.value].copy(),) if with_l1 else out
+
+
+def compute_stereo_matches(ex_left, ex_right, mbf, mb):
+    """Single stereo frame: call after ex_left(image_left) and ex_right(image_right).
+    Returns (mvuRight, mvDepth) as float32 arrays, -1 where there is no match."""
+    cap = ex_left.max_keypoints()
+    ur = np.empty(cap, np.float32)
+    dp = np.empty(cap, np.float32)
+    n = C.c_int32()
+    check(lib().orbx_stereo_match(ex_left._h, ex_right._h, float(mbf), float(mb), ptr(ur), ptr(dp), cap,
+                                  C.byref(n)), "orbx_stereo_match")
+    return ur[:n.value].copy(), dp[:n.value].copy()
+
+
 def shard_bounds(n_rows, world):
     """Contiguous train-row ranges [b[r], b[r+1]) per rank, starts aligned to 8 rows.
     Contiguous ranges keep global index order = (rank, local index) order, so merging

@@ -42,6 +42,9 @@ def lib():
         L.orc_stereo_band_match.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                             C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float,
                                             C.c_void_p, C.c_void_p]
+        L.orc_stereo_match.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                       C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
+                                       C.c_void_p]
         _lib = L
     return _lib
 
@@ -187,3 +190,19 @@ def stereo_band_match(kl, dl, kr, dr, scale_factors, n_rows, min_d, max_d):
     lib().orc_stereo_band_match(_p(kl), _p(dl), len(kl), _p(kr), _p(dr), len(kr), _p(sf), n_rows,
                                 min_d, max_d, _p(bi), _p(bd))
     return bi, bd
+
+
+def stereo_match(ex_l, ex_r, kl, dl, kr, dr, mbf, mb):
+    """Frame::ComputeStereoMatches on the pyramids of the last extract calls of ex_l / ex_r."""
+    kl = np.ascontiguousarray(kl, KP)
+    kr = np.ascontiguousarray(kr, KP)
+    dl = np.ascontiguousarray(dl, np.uint8)
+    dr = np.ascontiguousarray(dr, np.uint8)
+    n = len(kl)
+    ur = np.zeros(max(n, 1), np.float32)
+    dp = np.zeros(max(n, 1), np.float32)
+    sad = np.zeros(max(n, 1), np.int32)
+    st = lib().orc_stereo_match(ex_l.h, ex_r.h, _p(kl), _p(dl), n, _p(kr), _p(dr), len(kr), mbf, mb,
+                                _p(ur), _p(dp), _p(sad))
+    assert st == 0
+    return ur[:n], dp[:n], sad[:n]

@@ -216,3 +216,30 @@ def test_hamming_and_knn_oracle_against_numpy(oracle):
     assert idx[0].tolist() == [100, 200] and dist[0].tolist() == [0, 0]
     i1, d1 = oracle.knn2(q[:2], t[:1])
     assert i1[:, 1].tolist() == [0xFFFFFFFF] * 2 and d1[:, 1].tolist() == [0xFFFF] * 2
+
+
+def test_stereo_match_constant_disparity(oracle):
+    """Right image = left image shifted by 12 columns: every surviving match must report a
+    disparity of 12 within the sub-pixel step of its pyramid level, depth = mbf / disparity,
+    and the median rule (Frame.cc:984-995) must only ever remove matches."""
+    from orb_slam3_amd.synth import textured_frame
+    wide = textured_frame(3, 752 + 12, 480)
+    left = np.ascontiguousarray(wide[:, :752])
+    right = np.ascontiguousarray(wide[:, 12:])
+    params = (1000, 1.2, 8, 20, 7)
+    ol, orr = oracle.Extractor(*params), oracle.Extractor(*params)
+    _, _, kl, dl = ol.extract(left, (0, 0))
+    _, _, kr, dr = orr.extract(right, (0, 0))
+    mbf, mb = np.float32(47.9), np.float32(0.11)
+    ur, dp, sad = oracle.stereo_match(ol, orr, kl, dl, kr, dr, mbf, mb)
+    ok = dp > 0
+    assert ok.sum() > 300
+    disp = kl["x"][ok] - ur[ok]
+    scale = (np.float32(1.2) ** kl["octave"][ok]).astype(np.float32)
+    assert (np.abs(disp - 12) <= 1.01 * scale).all()
+    assert np.array_equal(dp[ok], (mbf / disp).astype(np.float32))
+    assert ((ur == -1) == (dp == -1)).all()
+    assert (sad[ok] >= 0).all()
+    removed = (sad >= 0) & ~ok
+    if removed.any():
+        assert sad[removed].min() >= sad[ok].max()
