@@ -145,13 +145,54 @@ def hamming_bench(torch, orbx, dev, nq=65536, nt=262144, reps=3):
                          "unit": "T lane-ops/s", "frac": pairs * 16 / peak_ops}}
 
 
+def stereo_bench(torch, orbx, dev, local_rank, batch=128, reps=5):
+    """Secondary metric: rectified stereo pairs/s (config: 752x480, 1200 kp per camera,
+    vLappingArea (0,0)): both extractions plus the device-resident ComputeStereoMatches
+    (band search, L1 refinement, depth, median rule), images resident in HBM."""
+    params = (1200, 1.2, 8, 20, 7)
+    distinct = 8
+    lefts = [orbx.textured_frame(500 + i, W, H) for i in range(distinct)]
+    rights = [orbx.right_view(l, 500 + i) for i, l in enumerate(lefts)]
+    reps_t = (batch + distinct - 1) // distinct
+    dl = torch.from_numpy(np.tile(np.stack(lefts), (reps_t, 1, 1))[:batch].copy()).to(dev)
+    dr = torch.from_numpy(np.tile(np.stack(rights), (reps_t, 1, 1))[:batch].copy()).to(dev)
+    exl = orbx.ORBextractor(*params, device=local_rank, max_batch=batch)
+    exr = orbx.ORBextractor(*params, device=local_rank, max_batch=batch)
+    mbf, mb = 435.2 * 0.11, 0.11
+
+    def run():
+        exl.extract_batch_device(dl.data_ptr(), batch, W, H, W, (0, 0))
+        exr.extract_batch_device(dr.data_ptr(), batch, W, H, W, (0, 0))
+        orbx.compute_stereo_matches_batch(exl, exr, batch, mbf, mb)
+    run()
+    exl.sync()
+    exr.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        run()
+    exl.sync()
+    exr.sync()
+    sec = (time.perf_counter() - t0) / reps
+    # stereo stage alone (extractions already done)
+    exl.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        orbx.compute_stereo_matches_batch(exl, exr, batch, mbf, mb)
+    exl.sync()
+    sec_match = (time.perf_counter() - t0) / reps
+    nmatch = float(np.mean([(orbx.stereo_download(exl, f)[1] > 0).sum() for f in range(min(batch, 8))]))
+    return {"metric": "stereo pairs/s @752x480, 2x1200kp, extraction + ComputeStereoMatches",
+            "value": batch / sec, "unit": "pairs/s", "pairs_per_step": batch, "ms_per_step": sec * 1e3,
+            "match_stage_ms_per_step": sec_match * 1e3, "matches_per_pair": nmatch}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=512, help="frames per step per GPU")
-    ap.add_argument("--no-match", action="store_true", help="skip the Hamming 2-NN leg")
+    ap.add_argument("--no-match", action="store_true", help="skip the Hamming 2-NN and stereo legs")
     ap.add_argument("--distinct", type=int, default=32, help="distinct synthetic frames (tiled to the batch)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     args = ap.parse_args()
@@ -244,6 +285,7 @@ def main():
         }
         if not args.no_match:
             out["hamming"] = hamming_bench(torch, orbx, dev)
+            out["stereo"] = stereo_bench(torch, orbx, dev, local_rank)
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames)
             out["gpu_over_cpu"] = fps / out["cpu_baseline"]["value"]

@@ -43,6 +43,18 @@ def main():
                             keypoints=k, descriptors=d, pyramid_crc32=np.array(pyr_crc, np.uint32),
                             ncand=np.array(ncand), image_crc32=zlib.crc32(img.tobytes()))
         print(name, len(k), mono, ncand)
+    # stereo association (Frame::ComputeStereoMatches) on a synthetic rectified pair
+    from tests.stereo_util import right_view
+    prm, seed, mbf, mb = (1200, 1.2, 8, 20, 7), 11, np.float32(435.2 * 0.11), np.float32(0.11)
+    left = orbx.textured_frame(seed, 752, 480)
+    right = right_view(left, seed)
+    el, er = O.Extractor(*prm), O.Extractor(*prm)
+    _, _, kl, dl = el.extract(left, (0, 0))
+    _, _, kr, dr = er.extract(right, (0, 0))
+    ur, dp, sad = O.stereo_match(el, er, kl, dl, kr, dr, mbf, mb)
+    np.savez_compressed(os.path.join(HERE, "pair_match_752x480.npz"), seed=seed, params=np.array(prm, np.float64),
+                        mbf=mbf, mb=mb, right_crc32=zlib.crc32(right.tobytes()), uright=ur, depth=dp, l1=sad)
+    print("pair_match", int((dp > 0).sum()), "matches of", len(kl))
     rng = np.random.default_rng(2024)
     t = rng.integers(0, 256, (3000, 32), dtype=np.uint8)
     t[1500:1600] = t[:100]  # duplicates: exact distance ties

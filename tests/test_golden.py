@@ -11,7 +11,8 @@ import pytest
 import orb_slam3_amd as orbx
 
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = sorted(p for p in glob.glob(os.path.join(HERE, "*.npz")) if "knn2" not in p)
+CASES = sorted(p for p in glob.glob(os.path.join(HERE, "*.npz"))
+               if "knn2" not in p and "pair_match" not in p)
 
 
 def load(path):
@@ -68,3 +69,35 @@ def test_hip_knn_golden():
     g = np.load(os.path.join(HERE, "knn2_200x3000.npz"))
     idx, dist = orbx.knn_match2(g["q"], g["t"])
     assert np.array_equal(idx, g["idx"]) and np.array_equal(dist, g["dist"])
+
+
+def _pair(g):
+    from tests.stereo_util import right_view
+    prm = g["params"]
+    params = (int(prm[0]), float(prm[1]), int(prm[2]), int(prm[3]), int(prm[4]))
+    left = orbx.textured_frame(int(g["seed"]), 752, 480)
+    right = right_view(left, int(g["seed"]))
+    assert zlib.crc32(right.tobytes()) == int(g["right_crc32"])
+    return params, left, right
+
+
+def test_oracle_pair_match_golden(oracle):
+    g = np.load(os.path.join(HERE, "pair_match_752x480.npz"))
+    params, left, right = _pair(g)
+    el, er = oracle.Extractor(*params), oracle.Extractor(*params)
+    _, _, kl, dl = el.extract(left, (0, 0))
+    _, _, kr, dr = er.extract(right, (0, 0))
+    ur, dp, l1 = oracle.stereo_match(el, er, kl, dl, kr, dr, float(g["mbf"]), float(g["mb"]))
+    assert np.array_equal(ur, g["uright"]) and np.array_equal(dp, g["depth"]) and np.array_equal(l1, g["l1"])
+
+
+@pytest.mark.gpu
+def test_hip_pair_match_golden():
+    g = np.load(os.path.join(HERE, "pair_match_752x480.npz"))
+    params, left, right = _pair(g)
+    exl, exr = orbx.ORBextractor(*params), orbx.ORBextractor(*params)
+    exl(left, None, (0, 0))
+    exr(right, None, (0, 0))
+    orbx.compute_stereo_matches_batch(exl, exr, 1, float(g["mbf"]), float(g["mb"]))
+    ur, dp, l1 = orbx.stereo_download(exl, 0, with_l1=True)
+    assert np.array_equal(ur, g["uright"]) and np.array_equal(dp, g["depth"]) and np.array_equal(l1, g["l1"])
