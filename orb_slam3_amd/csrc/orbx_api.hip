@@ -35,8 +35,9 @@ int octree_set_lds_limit(const Plan& hp);
 void launch_stereo(const Plan& hp, const Plan* dp, const uint8_t* pyrL, const uint8_t* pyrR,
                    const float* kpsL, const uint8_t* descL, const int* nL, int capL,
                    const float* kpsR, const uint8_t* descR, const int* nR, int capR, float mbf,
-                   float mb, int* bandIdx, int* bandDist, int* sadDist, float* uRight, float* depth,
-                   int nframes, hipStream_t s);
+                   float mb, int* rowStart, int* entries, int* bandIdx, int* bandDist, int* sadDist,
+                   float* uRight, float* depth, int nframes, hipStream_t s);
+int stereo_entries_per_keypoint(const Plan& hp);
 int launch_debug_sort(uint64_t* d_data, int n, hipStream_t s);
 }  // namespace orbx
 
@@ -115,6 +116,9 @@ struct orbx_extractor {
   size_t pyr_bytes = 0;
   // stereo association results of this (left) handle, allocated by the first stereo call
   int* d_stBandIdx = nullptr;
+  int* d_stRowStart = nullptr;   // row table of the right keypoints (CSR)
+  int* d_stEntries = nullptr;
+  int stRightCap = 0;            // right-handle keypoint capacity d_stEntries is sized for
   int* d_stBandDist = nullptr;
   int* d_stSad = nullptr;
   float* d_stURight = nullptr;
@@ -182,8 +186,9 @@ void orbx_extractor::freePlan() {
   (void)hipStreamSynchronize(stream);
   for (void* t : d_taps) (void)hipFree(t);
   d_taps.clear();
-  void* sbufs[] = {d_stBandIdx, d_stBandDist, d_stSad, d_stURight, d_stDepth};
+  void* sbufs[] = {d_stRowStart, d_stEntries, d_stBandIdx, d_stBandDist, d_stSad, d_stURight, d_stDepth};
   for (void* b : sbufs) if (b) (void)hipFree(b);
+  d_stRowStart = d_stEntries = nullptr; stRightCap = 0;
   d_stBandIdx = d_stBandDist = d_stSad = nullptr; d_stURight = d_stDepth = nullptr; stereoFrames = 0;
   void* bufs[] = {d_octws, dp, d_img, d_pyr, d_blur, d_cand, d_cellCount, d_flatA, d_flatB, d_sel, d_selCount,
                   d_kps, d_desc, d_work, d_n, d_mono};
@@ -683,11 +688,20 @@ int orbx_stereo_match_batch_device(orbx_extractor* left, orbx_extractor* right, 
   auto& last_hip_error = ex->last_hip_error;
   if (!ex->d_stURight) {
     const size_t slots = (size_t)ex->prm.max_batch * ex->hp.kp_cap;
+    HIP_TRY(hipMalloc((void**)&ex->d_stRowStart, (size_t)ex->prm.max_batch * (ex->hp.lv[0].h + 1) * 4));
     HIP_TRY(hipMalloc((void**)&ex->d_stBandIdx, slots * 4));
     HIP_TRY(hipMalloc((void**)&ex->d_stBandDist, slots * 4));
     HIP_TRY(hipMalloc((void**)&ex->d_stSad, slots * 4));
     HIP_TRY(hipMalloc((void**)&ex->d_stURight, slots * 4));
     HIP_TRY(hipMalloc((void**)&ex->d_stDepth, slots * 4));
+  }
+  if (right->hp.kp_cap > ex->stRightCap) {
+    HIP_TRY(hipStreamSynchronize(ex->stream));
+    if (ex->d_stEntries) HIP_TRY(hipFree(ex->d_stEntries));
+    ex->d_stEntries = nullptr;
+    HIP_TRY(hipMalloc((void**)&ex->d_stEntries, (size_t)ex->prm.max_batch * right->hp.kp_cap *
+                                                    orbx::stereo_entries_per_keypoint(ex->hp) * 4));
+    ex->stRightCap = right->hp.kp_cap;
   }
   if (!ex->evStereo) HIP_TRY(hipEventCreateWithFlags(&ex->evStereo, hipEventDisableTiming));
   // the right extraction runs on its own stream: order this work after it
@@ -695,7 +709,7 @@ int orbx_stereo_match_batch_device(orbx_extractor* left, orbx_extractor* right, 
   HIP_TRY(hipStreamWaitEvent(ex->stream, ex->evStereo, 0));
   orbx::launch_stereo(ex->hp, ex->dp, ex->d_pyr, right->d_pyr, ex->d_kps, ex->d_desc, ex->d_n,
                       ex->hp.kp_cap, right->d_kps, right->d_desc, right->d_n, right->hp.kp_cap, mbf, mb,
-                      ex->d_stBandIdx, ex->d_stBandDist, ex->d_stSad, ex->d_stURight, ex->d_stDepth,
+                      ex->d_stRowStart, ex->d_stEntries, ex->d_stBandIdx, ex->d_stBandDist, ex->d_stSad, ex->d_stURight, ex->d_stDepth,
                       n_frames, ex->stream);
   HIP_TRY(hipGetLastError());
   // the right handle's buffers must not be overwritten before this work has read them

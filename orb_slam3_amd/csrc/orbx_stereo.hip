@@ -1,6 +1,7 @@
 // Stereo association of two extractions that are still resident on the device:
 // Frame::ComputeStereoMatches, core/src/Frame.cc:831-996.
-//   k_stereo_band_batch   row-band descriptor search             :840-908
+//   k_stereo_rows         row table of the right keypoints       :840-856
+//   k_stereo_band_batch   row-band descriptor search             :867-908
 //   k_stereo_refine       11x11 L1 search over +-5 columns on the
 //                         pyramid level of the left keypoint,
 //                         parabola fit, disparity and depth      :910-981
@@ -17,50 +18,116 @@ namespace orbx {
 
 struct SKP { float x, y, size, angle, response; int octave, class_id; };
 
-// One lane per left keypoint; right keypoints are visited in ascending index (wave-uniform
-// loads), so the first minimum wins as in the reference's row buckets, which hold ascending
-// right indices.
+// Row table of the right keypoints (Frame.cc:840-856) as a CSR: rowStart[r] .. rowStart[r+1]
+// index the right keypoints whose band floor(y - r) .. ceil(y + r), r = 2 * scale[octave],
+// contains row r.  One block per frame; counts and cursors live in LDS.  The order inside a row
+// is whatever the atomics produce: the search below takes the minimum of (distance, index),
+// which is what "first strict minimum in ascending index" selects.
+__global__ __launch_bounds__(256) void k_stereo_rows(const Plan* __restrict__ plan,
+                                                     const SKP* __restrict__ kpsR,
+                                                     const int* __restrict__ nRp, int capR,
+                                                     int entriesPerFrame, int* __restrict__ rowStart,
+                                                     int* __restrict__ entries) {
+  extern __shared__ int sRows[];          // cnt[nRows] then partial[256]
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const int nRows = plan->lv[0].h, nR = nRp[f];
+  int* cnt = sRows;
+  int* part = sRows + nRows;
+  const SKP* kr = kpsR + (size_t)f * capR;
+  for (int r = tid; r < nRows; r += 256) cnt[r] = 0;
+  __syncthreads();
+  for (int j = tid; j < nR; j += 256) {
+    const float y = kr[j].y, rad = __fmul_rn(2.0f, plan->lv[kr[j].octave].scale);
+    const int maxr = min((int)ceilf(__fadd_rn(y, rad)), nRows - 1);
+    const int minr = max((int)floorf(__fsub_rn(y, rad)), 0);
+    for (int r = minr; r <= maxr; ++r) atomicAdd(&cnt[r], 1);
+  }
+  __syncthreads();
+  // exclusive scan: each thread owns a contiguous run of rows
+  const int per = (nRows + 255) / 256;
+  const int r0 = min(tid * per, nRows), r1 = min(r0 + per, nRows);
+  int sum = 0;
+  for (int r = r0; r < r1; ++r) sum += cnt[r];
+  part[tid] = sum;
+  __syncthreads();
+  if (tid < 64) {   // wave 0 scans the 256 partial sums, 4 per lane
+    int v[4], t = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { v[u] = part[tid * 4 + u]; t += v[u]; }
+    int inc = t;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(inc, d);
+      if (tid >= d) inc += o;
+    }
+    int run = inc - t;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { part[tid * 4 + u] = run; run += v[u]; }
+  }
+  __syncthreads();
+  int run = part[tid];
+  int* rs = rowStart + (size_t)f * (nRows + 1);
+  for (int r = r0; r < r1; ++r) {
+    const int c = cnt[r];
+    rs[r] = run;
+    cnt[r] = run;       // becomes the fill cursor
+    run += c;
+  }
+  if (tid == 255) rs[nRows] = run;   // threads past the last row own nothing: run = total
+  __syncthreads();
+  int* ent = entries + (size_t)f * entriesPerFrame;
+  for (int j = tid; j < nR; j += 256) {
+    const float y = kr[j].y, rad = __fmul_rn(2.0f, plan->lv[kr[j].octave].scale);
+    const int maxr = min((int)ceilf(__fadd_rn(y, rad)), nRows - 1);
+    const int minr = max((int)floorf(__fsub_rn(y, rad)), 0);
+    for (int r = minr; r <= maxr; ++r) {
+      const int pos = atomicAdd(&cnt[r], 1);
+      if (pos < entriesPerFrame) ent[pos] = j;
+    }
+  }
+}
+
+// One lane per left keypoint over the candidates of its row (Frame.cc:867-908).
 __global__ __launch_bounds__(256) void k_stereo_band_batch(
-    const Plan* __restrict__ plan, const SKP* __restrict__ kpsL, const uint32_t* __restrict__ descL,
-    const int* __restrict__ nLp, const SKP* __restrict__ kpsR, const uint32_t* __restrict__ descR,
-    const int* __restrict__ nRp, int capL, int capR, float minD, float maxD,
-    int* __restrict__ bestIdx, int* __restrict__ bestDist) {
+    const Plan* __restrict__ plan, const SKP* __restrict__ kpsL, const uint4* __restrict__ descL,
+    const int* __restrict__ nLp, const SKP* __restrict__ kpsR, const uint4* __restrict__ descR,
+    int capL, int capR, float minD, float maxD, int entriesPerFrame,
+    const int* __restrict__ rowStart, const int* __restrict__ entries, int* __restrict__ bestIdx,
+    int* __restrict__ bestDist) {
   const int f = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;
-  const int nL = nLp[f], nR = nRp[f];
-  if (blockIdx.x * 256 >= nL) return;
-  const bool valid = i < nL;
-  const SKP* kl = kpsL + (size_t)f * capL;
+  const int nL = nLp[f];
+  if (i >= nL) return;
   const SKP* kr = kpsR + (size_t)f * capR;
-  const uint32_t* dl = descL + (size_t)f * capL * 8;
-  const uint32_t* dr = descR + (size_t)f * capR * 8;
+  const uint4* dr = descR + (size_t)f * capR * 2;
   const int nRows = plan->lv[0].h;
-  SKP L = kl[valid ? i : 0];
-  uint32_t a[8];
-#pragma unroll
-  for (int w = 0; w < 8; ++w) a[w] = dl[(size_t)(valid ? i : 0) * 8 + w];
+  const SKP L = kpsL[(size_t)f * capL + i];
+  const uint4 a0 = descL[((size_t)f * capL + i) * 2], a1 = descL[((size_t)f * capL + i) * 2 + 1];
   const int row = (int)L.y;
   const float minU = __fsub_rn(L.x, maxD), maxU = __fsub_rn(L.x, minD);
-  int best = 100, bi = -1;
-  const bool live = valid && row >= 0 && row < nRows && !(maxU < 0.f);
-  for (int j = 0; j < nR; ++j) {
-    const SKP R = kr[j];
-    const float r = __fmul_rn(2.0f, plan->lv[R.octave].scale);
-    const int maxr = (int)ceilf(__fadd_rn(R.y, r));
-    const int minr = (int)floorf(__fsub_rn(R.y, r));
-    bool ok = live && row >= minr && row <= maxr;
-    ok = ok && R.octave >= L.octave - 1 && R.octave <= L.octave + 1;
-    ok = ok && R.x >= minU && R.x <= maxU;
-    if (__ballot(ok) == 0ull) continue;
-    int d = 0;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) d += __builtin_popcount(a[w] ^ dr[(size_t)j * 8 + w]);
-    if (ok && d < best) { best = d; bi = j; }
+  const uint32_t none = 100u << 20;          // TH_HIGH, no index
+  uint32_t best = none;
+  if (row >= 0 && row < nRows && !(maxU < 0.f)) {
+    const int* rs = rowStart + (size_t)f * (nRows + 1);
+    const int* ent = entries + (size_t)f * entriesPerFrame;
+    const int e0 = rs[row], e1 = min(rs[row + 1], entriesPerFrame);
+    for (int e = e0; e < e1; ++e) {
+      const int j = ent[e];
+      const float xr = kr[j].x;
+      const int octR = kr[j].octave;
+      if (octR < L.octave - 1 || octR > L.octave + 1) continue;
+      if (!(xr >= minU && xr <= maxU)) continue;
+      const uint4 b0 = dr[(size_t)j * 2], b1 = dr[(size_t)j * 2 + 1];
+      const int d = __builtin_popcount(a0.x ^ b0.x) + __builtin_popcount(a0.y ^ b0.y) +
+                    __builtin_popcount(a0.z ^ b0.z) + __builtin_popcount(a0.w ^ b0.w) +
+                    __builtin_popcount(a1.x ^ b1.x) + __builtin_popcount(a1.y ^ b1.y) +
+                    __builtin_popcount(a1.z ^ b1.z) + __builtin_popcount(a1.w ^ b1.w);
+      const uint32_t key = ((uint32_t)d << 20) | (uint32_t)j;
+      best = key < best ? key : best;
+    }
   }
-  if (valid) {
-    bestIdx[(size_t)f * capL + i] = bi;
-    bestDist[(size_t)f * capL + i] = best;
-  }
+  bestIdx[(size_t)f * capL + i] = best < none ? (int)(best & 0xFFFFF) : -1;
+  bestDist[(size_t)f * capL + i] = best < none ? (int)(best >> 20) : 100;
 }
 
 // 16 lanes per left keypoint, 4 keypoints per wave: lane j < 11 evaluates the shift incR = j - 5.
@@ -195,16 +262,24 @@ __global__ __launch_bounds__(256) void k_stereo_outliers(const int* __restrict__
   }
 }
 
+// Row-table entries one right keypoint can produce: band = floor(y - r) .. ceil(y + r), r = 2 * scale.
+int stereo_entries_per_keypoint(const Plan& hp) {
+  return (int)(4.0f * hp.lv[hp.nlevels - 1].scale) + 3;
+}
+
 void launch_stereo(const Plan& hp, const Plan* dp, const uint8_t* pyrL, const uint8_t* pyrR,
                    const float* kpsL, const uint8_t* descL, const int* nL, int capL,
                    const float* kpsR, const uint8_t* descR, const int* nR, int capR, float mbf,
-                   float mb, int* bandIdx, int* bandDist, int* sadDist, float* uRight, float* depth,
-                   int nframes, hipStream_t s) {
-  (void)hp;
+                   float mb, int* rowStart, int* entries, int* bandIdx, int* bandDist, int* sadDist,
+                   float* uRight, float* depth, int nframes, hipStream_t s) {
   const float minD = 0.f, maxD = mbf / mb;   // Frame.cc:859-861
+  const int nRows = hp.lv[0].h;
+  const int entriesPerFrame = capR * stereo_entries_per_keypoint(hp);
+  hipLaunchKernelGGL(k_stereo_rows, dim3(nframes), dim3(256), (size_t)(nRows + 256) * 4, s, dp,
+                     (const SKP*)kpsR, nR, capR, entriesPerFrame, rowStart, entries);
   hipLaunchKernelGGL(k_stereo_band_batch, dim3((capL + 255) / 256, nframes), dim3(256), 0, s, dp,
-                     (const SKP*)kpsL, (const uint32_t*)descL, nL, (const SKP*)kpsR,
-                     (const uint32_t*)descR, nR, capL, capR, minD, maxD, bandIdx, bandDist);
+                     (const SKP*)kpsL, (const uint4*)descL, nL, (const SKP*)kpsR, (const uint4*)descR,
+                     capL, capR, minD, maxD, entriesPerFrame, rowStart, entries, bandIdx, bandDist);
   hipLaunchKernelGGL(k_stereo_refine, dim3((capL + 15) / 16, nframes), dim3(256), 0, s, dp, pyrL, pyrR,
                      (const SKP*)kpsL, nL, (const SKP*)kpsR, capL, capR, bandIdx, bandDist, mbf, minD,
                      maxD, uRight, depth, sadDist);
