@@ -127,8 +127,13 @@ struct orbx_extractor {
   hipEvent_t evStereo = nullptr;
 
   // pinned host staging
-  uint8_t* h_stage = nullptr;
-  size_t h_stage_bytes = 0;
+  // pinned host staging for the host-pointer entry points: two input buffers of stageFrames
+  // images each (filled by the CPU while the other one is in flight) and one output buffer
+  uint8_t* h_in[2] = {nullptr, nullptr};
+  uint8_t* h_out = nullptr;
+  int stageFrames = 0;
+  hipEvent_t evIn[2] = {nullptr, nullptr};
+  bool evInUsed[2] = {false, false};
   std::vector<uint8_t> h_pyr;       // lazily downloaded pyramid of frame 0
   std::vector<char> h_pyr_valid;
 
@@ -195,8 +200,9 @@ void orbx_extractor::freePlan() {
   for (void* b : bufs) if (b) (void)hipFree(b);
   dp = nullptr; d_img = d_pyr = d_blur = d_desc = nullptr; d_cand = d_flatA = d_flatB = d_sel = nullptr;
   d_cellCount = d_selCount = d_n = d_mono = nullptr; d_octws = nullptr; d_kps = nullptr; d_work = nullptr;
-  if (h_stage) (void)hipHostFree(h_stage);
-  h_stage = nullptr; h_stage_bytes = 0;
+  for (int i = 0; i < 2; ++i) { if (h_in[i]) (void)hipHostFree(h_in[i]); h_in[i] = nullptr; evInUsed[i] = false; }
+  if (h_out) (void)hipHostFree(h_out);
+  h_out = nullptr; stageFrames = 0;
   planned = false;
 }
 
@@ -427,8 +433,10 @@ int orbx_extractor::ensurePlan(int W, int H) {
   HIP_TRY(hipMalloc((void**)&d_work, (size_t)B * hp.kp_cap * sizeof(WorkItem)));
   HIP_TRY(hipMalloc((void**)&d_n, (size_t)B * 4));
   HIP_TRY(hipMalloc((void**)&d_mono, (size_t)B * 4));
-  h_stage_bytes = std::max((size_t)W * H, (size_t)hp.kp_cap * 60 + 64);
-  HIP_TRY(hipHostMalloc((void**)&h_stage, h_stage_bytes, hipHostMallocDefault));
+  stageFrames = std::min(B, 16);
+  for (int i = 0; i < 2; ++i)
+    HIP_TRY(hipHostMalloc((void**)&h_in[i], (size_t)stageFrames * W * H, hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void**)&h_out, (size_t)stageFrames * (hp.kp_cap * 60 + 8), hipHostMallocDefault));
   h_pyr.clear();
   h_pyr_valid.assign(nl, 0);
   return ORBX_OK;
@@ -538,6 +546,7 @@ void orbx_destroy(orbx_extractor* ex) {
   }
   if (ex->evFork) (void)hipEventDestroy(ex->evFork);
   if (ex->evStereo) (void)hipEventDestroy(ex->evStereo);
+  for (int i = 0; i < 2; ++i) if (ex->evIn[i]) (void)hipEventDestroy(ex->evIn[i]);
   if (ex->stream) (void)hipStreamDestroy(ex->stream);
   delete ex;
 }
@@ -636,22 +645,50 @@ int orbx_extract_batch(orbx_extractor* ex, int n_frames, const uint8_t* const* i
   if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
   int st = ex->ensurePlan(width, height);
   if (st != ORBX_OK) { ex->freePlan(); return st; }
+  auto& last_hip_error = ex->last_hip_error;
   hipStream_t s = ex->stream;
-  for (int f = 0; f < n_frames; ++f) {
-    hipError_t e = hipMemcpy2DAsync(ex->d_img + (size_t)f * width * height, width, imgs[f], stride,
-                                    width, height, hipMemcpyHostToDevice, s);
-    if (e != hipSuccess) { ex->last_hip_error = e; return ORBX_ERR_HIP; }
+  const size_t frameBytes = (size_t)width * height;
+  const int CH = ex->stageFrames;
+  // images: rows are packed into a pinned buffer by the CPU (a pageable 2-D copy would be
+  // split into one transfer per row), then one transfer per group of frames
+  for (int c0 = 0, k = 0; c0 < n_frames; c0 += CH, ++k) {
+    const int b = k & 1, c1 = std::min(c0 + CH, n_frames);
+    if (!ex->evIn[b]) HIP_TRY(hipEventCreateWithFlags(&ex->evIn[b], hipEventDisableTiming));
+    if (ex->evInUsed[b]) HIP_TRY(hipEventSynchronize(ex->evIn[b]));
+    for (int f = c0; f < c1; ++f) {
+      uint8_t* dst = ex->h_in[b] + (size_t)(f - c0) * frameBytes;
+      if (stride == width) std::memcpy(dst, imgs[f], frameBytes);
+      else for (int y = 0; y < height; ++y) std::memcpy(dst + (size_t)y * width, imgs[f] + (size_t)y * stride, width);
+    }
+    HIP_TRY(hipMemcpyAsync(ex->d_img + (size_t)c0 * frameBytes, ex->h_in[b], (size_t)(c1 - c0) * frameBytes,
+                           hipMemcpyHostToDevice, s));
+    HIP_TRY(hipEventRecord(ex->evIn[b], s));
+    ex->evInUsed[b] = true;
   }
-  st = ex->run(ex->d_img, width, (size_t)width * height, n_frames, lap0, lap1);
+  st = ex->run(ex->d_img, width, frameBytes, n_frames, lap0, lap1);
   if (st != ORBX_OK) return st;
+  // results: counts first, then whole groups of keypoint / descriptor slots through pinned memory
   int worst = ORBX_OK;
-  for (int f = 0; f < n_frames; ++f) {
-    int n = 0, mono = 0;
-    st = orbx_batch_download(ex, f, kps ? kps + (size_t)f * cap : nullptr,
-                             desc ? desc + (size_t)f * cap * 32 : nullptr, cap, &n, &mono);
-    if (n_out) n_out[f] = n;
-    if (mono_out) mono_out[f] = mono;
-    if (st != ORBX_OK) worst = st;
+  const int kc = ex->hp.kp_cap;
+  for (int c0 = 0; c0 < n_frames; c0 += CH) {
+    const int c1 = std::min(c0 + CH, n_frames), m = c1 - c0;
+    int* hn = (int*)ex->h_out;
+    int* hm = hn + CH;
+    uint8_t* hk = ex->h_out + (size_t)CH * 8;
+    uint8_t* hd = hk + (size_t)CH * kc * 28;
+    HIP_TRY(hipMemcpyAsync(hn, ex->d_n + c0, (size_t)m * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(hm, ex->d_mono + c0, (size_t)m * 4, hipMemcpyDeviceToHost, s));
+    if (kps) HIP_TRY(hipMemcpyAsync(hk, ex->d_kps + (size_t)c0 * kc * 7, (size_t)m * kc * 28, hipMemcpyDeviceToHost, s));
+    if (desc) HIP_TRY(hipMemcpyAsync(hd, ex->d_desc + (size_t)c0 * kc * 32, (size_t)m * kc * 32, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (int f = c0; f < c1; ++f) {
+      const int n = hn[f - c0];
+      if (n_out) n_out[f] = n;
+      if (mono_out) mono_out[f] = hm[f - c0];
+      if (n > cap) { worst = ORBX_ERR_CAPACITY; continue; }
+      if (kps) std::memcpy(kps + (size_t)f * cap, hk + (size_t)(f - c0) * kc * 28, (size_t)n * 28);
+      if (desc) std::memcpy(desc + (size_t)f * cap * 32, hd + (size_t)(f - c0) * kc * 32, (size_t)n * 32);
+    }
   }
   return worst;
 }
