@@ -123,3 +123,17 @@ def test_stereo_argument_errors():
     with pytest.raises(OrbxError):
         orbx.compute_stereo_matches(a, b, MBF, 0.0)
     orbx.compute_stereo_matches(a, b, MBF, MB)
+
+
+def test_cv_adaptor_binary():
+    """include/orbx_cv.hpp (ORBextractor / DescriptorDistance / ComputeStereoMatches / KnnMatch2
+    with OpenCV-style types) gives the same bytes as the C ABI it wraps.  The binary is built by
+    __graft_entry__.build() against the test-only OpenCV stand-in in tests/cpp/cvstub."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "_build", "test_adaptor")
+    if not os.path.exists(exe):       # normally prebuilt; a two-second host compile otherwise
+        import __graft_entry__
+        __graft_entry__.build_adaptor_test()
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=100)
+    assert out.returncode == 0 and out.stdout.startswith("ok"), out.stdout + out.stderr

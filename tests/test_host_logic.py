@@ -68,6 +68,14 @@ def test_std_sort_restatement_matches_libstdcxx(tmp_path):
     assert out.startswith("OK")
 
 
+def test_cv_adaptor_header_compiles():
+    """include/orbx_cv.hpp against the test-only OpenCV stand-in (syntax and types only)."""
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror",
+                           "-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.join(ROOT, "tests", "cpp", "cvstub"),
+                           os.path.join(ROOT, "tests", "cpp", "test_adaptor.cpp")])
+
+
 def test_shard_bounds_cover_everything_once():
     import orb_slam3_amd as orbx
     for n in (0, 1, 7, 1000, 10_000_001):
