@@ -64,7 +64,13 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 // re-base them with v_alignbyte; groups that touch the border go per byte.
 // ---------------------------------------------------------------------------
 struct __attribute__((packed, aligned(4))) U4A4 { uint32_t x, y, z, w; };
+struct __attribute__((packed, aligned(4))) U3A4 { uint32_t x, y, z; };
 #define L0_ROWS 4  // rows per lane
+
+// High 32 bits of the product of two values below 2^24 (v_mul_hi_u32_u24).
+__device__ __forceinline__ uint32_t mul_hi_u24(uint32_t a, uint32_t b) {
+  return (uint32_t)(((uint64_t)(a & 0xFFFFFFu) * (uint64_t)(b & 0xFFFFFFu)) >> 32);
+}
 
 // Workgroups are handed to the 8 XCDs round-robin by linear id and every XCD has a private
 // L2.  For a 1-D launch of 8 * chunk workgroups this returns a work unit such that each XCD
@@ -140,72 +146,83 @@ __global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t* __restrict__ 
 // The tap tables are indexed by padded destination coordinates, so border
 // pixels are produced by the same code as interior ones.
 //
-// A block produces a 256 x 16 tile of the padded destination plane; the columns
-// in the reflected border or at the clamped right edge are produced by one
-// extra block per tile row through the per-pixel tap table, so that no wave
-// mixes the two code paths.
+// One wave per workgroup.  A main wave owns 64 destination dword columns (256
+// pixels) and 4 * groups rows, walked 4 rows at a time with the next step's
+// source rows already in flight: the stage is bound by memory latency, not by
+// bytes or arithmetic, so every wave keeps two steps of independent loads
+// outstanding and reuses its column record for all rows.  Columns in the
+// reflected border or at the clamped right edge go through the per-pixel tap
+// table in separate border waves, so that no wave mixes the two code paths.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pyr_resize(const uint8_t* __restrict__ src, int sstride,
-                                                    size_t splane, uint8_t* __restrict__ dst,
-                                                    int pstride, int prows, size_t dplane, int pw,
-                                                    const Tap* __restrict__ xtab,
-                                                    const Tap* __restrict__ ytab,
-                                                    const ColRec* __restrict__ colrec,
-                                                    const uint16_t* __restrict__ bcols, int nbc, int nbx,
-                                                    int f0) {
-  const int tid = threadIdx.y * 64 + threadIdx.x;
-  const int f = blockIdx.z + f0;
-  if ((int)blockIdx.x >= nbx) {
-    // border block: one lane per (row, border dword); taps straight from the tables,
-    // source bytes straight from the (cache-resident) source plane
-    const uint8_t* roi = src + (size_t)f * splane + (size_t)ORBX_EDGE * sstride + ORBX_EDGE;
-    const float rnb = 1.0f / (float)nbc;
-    for (int t = tid; t < 16 * nbc; t += 256) {
-      const int r = (int)(((float)t + 0.5f) * rnb);
-      const int py = blockIdx.y * 16 + r;
-      if (py >= prows) break;
-      const int c = bcols[t - r * nbc];
-      const Tap ty = ytab[py];
-      const uint8_t* r0 = roi + (size_t)ty.s0 * sstride;
-      const uint8_t* r1 = roi + (size_t)ty.s1 * sstride;
-      uint32_t out = 0;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int px = 4 * c + k;
-        const Tap tx = xtab[min(px, pw - 1)];
-        const uint32_t h0 = __umul24(r0[tx.s0], (uint32_t)(int)tx.w0) + __umul24(r0[tx.s1], (uint32_t)(int)tx.w1);
-        const uint32_t h1 = __umul24(r1[tx.s0], (uint32_t)(int)tx.w0) + __umul24(r1[tx.s1], (uint32_t)(int)tx.w1);
-        const uint32_t v = ((__umul24((uint32_t)(int)ty.w0, h0 >> 4) >> 16) +
-                            (__umul24((uint32_t)(int)ty.w1, h1 >> 4) >> 16) + 2u) >> 2;
-        out |= (px < pw ? (v & 0xFFu) : 0u) << (8 * k);
-      }
-      *(uint32_t*)(dst + (size_t)f * dplane + (size_t)py * pstride + 4 * c) = out;
-    }
-    return;
-  }
-  // main blocks: one lane = one destination dword column (4 pixels) x 4 rows.  The 8
-  // source bytes that hold all taps of the 4 pixels are fetched per source row as three
-  // dword-aligned words straight from the source plane (neighbouring lanes overlap, so
-  // the vector cache serves most of it), re-based with v_alignbyte, and each pixel's
-  // tap pair is picked with one v_perm_b32.  All loads of a lane are independent.
-  const int c = blockIdx.x * 64 + threadIdx.x;
-  if (c * 4 >= pstride) return;
-  const ColRec cr = colrec[c];
-  if (!(cr.deltas & 0x8000)) return;   // border column: done by the border block
-  const int py0 = blockIdx.y * 16 + threadIdx.y * 4;
-  Tap tys[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) tys[r] = ytab[min(py0 + r, prows - 1)];
-  const int sh = (ORBX_EDGE + (int)cr.sxa) & 3;   // planes and rows are 64-byte aligned
-  const uint8_t* base = src + (size_t)f * splane + (size_t)ORBX_EDGE * sstride + (ORBX_EDGE + (int)cr.sxa - sh);
-  uint32_t ra[4][3], rb[4][3];
+struct ResizeRows {
+  uint32_t a[4][3], b[4][3];   // upper / lower source row of 4 destination rows
+  uint32_t wy0[4], wy1[4];     // vertical weights << 12
+};
+
+__device__ __forceinline__ void resize_fetch(ResizeRows& R, const uint8_t* base, int sstride,
+                                             const Tap* tys) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const uint32_t* p0 = (const uint32_t*)(base + (size_t)tys[r].s0 * sstride);
-    const uint32_t* p1 = (const uint32_t*)(base + (size_t)tys[r].s1 * sstride);
-    ra[r][0] = p0[0]; ra[r][1] = p0[1]; ra[r][2] = p0[2];
-    rb[r][0] = p1[0]; rb[r][1] = p1[1]; rb[r][2] = p1[2];
+    // one 12-byte load per source row (dword-aligned)
+    const U3A4 a = *(const U3A4*)(base + (size_t)tys[r].s0 * sstride);
+    const U3A4 b = *(const U3A4*)(base + (size_t)tys[r].s1 * sstride);
+    R.a[r][0] = a.x; R.a[r][1] = a.y; R.a[r][2] = a.z;
+    R.b[r][0] = b.x; R.b[r][1] = b.y; R.b[r][2] = b.z;
+    // (b * (H >> 4)) >> 16 is the high word of the 24-bit product (b << 12) * (H & ~15)
+    R.wy0[r] = (uint32_t)(int)tys[r].w0 << 12;
+    R.wy1[r] = (uint32_t)(int)tys[r].w1 << 12;
   }
+}
+
+template <int GROUPS>
+__global__ __launch_bounds__(64) void k_pyr_resize(const uint8_t* __restrict__ src, int sstride,
+                                                   size_t splane, uint8_t* __restrict__ dst,
+                                                   int pstride, int prows, size_t dplane, int pw,
+                                                   const Tap* __restrict__ xtab,
+                                                   const Tap* __restrict__ ytab,
+                                                   const ColRec* __restrict__ colrec,
+                                                   const uint16_t* __restrict__ bcols, int nbc, int nbx,
+                                                   int f0) {
+  const int lane = threadIdx.x;
+  const int f = blockIdx.z + f0;
+  constexpr int rowsPerWave = 4 * GROUPS;
+  if ((int)blockIdx.x >= nbx) {
+    // border wave: one lane per (row, border dword); taps straight from the tables,
+    // source bytes straight from the (cache-resident) source plane
+    const uint8_t* roi = src + (size_t)f * splane + (size_t)ORBX_EDGE * sstride + ORBX_EDGE;
+    const int t = ((int)blockIdx.x - nbx) * 64 + lane;
+    if (t >= rowsPerWave * nbc) return;
+    const int r = (int)(((float)t + 0.5f) * (1.0f / (float)nbc));
+    const int py = blockIdx.y * rowsPerWave + r;
+    if (py >= prows) return;
+    const int c = bcols[t - r * nbc];
+    const Tap ty = ytab[py];
+    const uint8_t* r0 = roi + (size_t)ty.s0 * sstride;
+    const uint8_t* r1 = roi + (size_t)ty.s1 * sstride;
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int px = 4 * c + k;
+      const Tap tx = xtab[min(px, pw - 1)];
+      const uint32_t h0 = __umul24(r0[tx.s0], (uint32_t)(int)tx.w0) + __umul24(r0[tx.s1], (uint32_t)(int)tx.w1);
+      const uint32_t h1 = __umul24(r1[tx.s0], (uint32_t)(int)tx.w0) + __umul24(r1[tx.s1], (uint32_t)(int)tx.w1);
+      const uint32_t v = ((__umul24((uint32_t)(int)ty.w0, h0 >> 4) >> 16) +
+                          (__umul24((uint32_t)(int)ty.w1, h1 >> 4) >> 16) + 2u) >> 2;
+      out |= (px < pw ? (v & 0xFFu) : 0u) << (8 * k);
+    }
+    *(uint32_t*)(dst + (size_t)f * dplane + (size_t)py * pstride + 4 * c) = out;
+    return;
+  }
+  // main waves: one lane = one destination dword column (4 pixels).  The 8 source bytes that
+  // hold all taps of the 4 pixels are fetched per source row as three dword-aligned words
+  // (neighbouring lanes overlap, the vector cache serves most of it), re-based with
+  // v_alignbyte, and each pixel's tap pair is picked with one v_perm_b32.
+  const int c = blockIdx.x * 64 + lane;
+  if (c * 4 >= pstride) return;
+  const ColRec cr = colrec[c];
+  if (!(cr.deltas & 0x8000)) return;   // border column: done by the border waves
+  const int sh = (ORBX_EDGE + (int)cr.sxa) & 3;   // planes and rows are 64-byte aligned
+  const uint8_t* base = src + (size_t)f * splane + (size_t)ORBX_EDGE * sstride + (ORBX_EDGE + (int)cr.sxa - sh);
   uint32_t sel[4], wp[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -214,24 +231,37 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const uint8_t* __restrict__ 
     wp[k] = (2048u - cr.w1[k]) | ((uint32_t)cr.w1[k] << 16);  // (left, right) weights
   }
   uint8_t* dcol = dst + (size_t)f * dplane + 4 * c;
+  const int pyBase = blockIdx.y * rowsPerWave;
+  // the row taps of all steps first: wave-uniform, read before any store so that they can
+  // come through the scalar cache
+  Tap tys[rowsPerWave];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int py = py0 + r;
-    if (py < prows) {
-      const uint32_t alo = __builtin_amdgcn_alignbyte(ra[r][1], ra[r][0], sh), ahi = __builtin_amdgcn_alignbyte(ra[r][2], ra[r][1], sh);
-      const uint32_t blo = __builtin_amdgcn_alignbyte(rb[r][1], rb[r][0], sh), bhi = __builtin_amdgcn_alignbyte(rb[r][2], rb[r][1], sh);
-      const uint32_t wy0 = (uint32_t)(int)tys[r].w0, wy1 = (uint32_t)(int)tys[r].w1;  // 0..2048
-      uint32_t out = 0;
+  for (int r = 0; r < rowsPerWave; ++r) tys[r] = ytab[min(pyBase + r, prows - 1)];
+  ResizeRows buf[2];
+  resize_fetch(buf[0], base, sstride, tys);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        // horizontal: S[sx]*a0 + S[sx+1]*a1 (<= 255*2048); vertical: the 8-bit
-        // specialisation's ((b*(H>>4))>>16 + ... + 2) >> 2, all operands < 2^24
-        const uint32_t h0 = udot2(__builtin_amdgcn_perm(ahi, alo, sel[k]), wp[k], 0u);
-        const uint32_t h1 = udot2(__builtin_amdgcn_perm(bhi, blo, sel[k]), wp[k], 0u);
-        const uint32_t v = ((__umul24(wy0, h0 >> 4) >> 16) + (__umul24(wy1, h1 >> 4) >> 16) + 2u) >> 2;
-        out |= (v & 0xFFu) << (8 * k);
+  for (int g = 0; g < GROUPS; ++g) {
+    const int py0 = pyBase + 4 * g;
+    if (py0 >= prows) break;
+    if (g + 1 < GROUPS) resize_fetch(buf[(g + 1) & 1], base, sstride, tys + 4 * (g + 1));
+    const ResizeRows& cur = buf[g & 1];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int py = py0 + r;
+      if (py < prows) {
+        const uint32_t alo = __builtin_amdgcn_alignbyte(cur.a[r][1], cur.a[r][0], sh), ahi = __builtin_amdgcn_alignbyte(cur.a[r][2], cur.a[r][1], sh);
+        const uint32_t blo = __builtin_amdgcn_alignbyte(cur.b[r][1], cur.b[r][0], sh), bhi = __builtin_amdgcn_alignbyte(cur.b[r][2], cur.b[r][1], sh);
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          // horizontal: S[sx]*a0 + S[sx+1]*a1 (<= 255*2048 < 2^20); vertical: the 8-bit
+          // specialisation's ((b*(H>>4))>>16 + ... + 2) >> 2 (<= 255)
+          const uint32_t h0 = udot2(__builtin_amdgcn_perm(ahi, alo, sel[k]), wp[k], 0u);
+          const uint32_t h1 = udot2(__builtin_amdgcn_perm(bhi, blo, sel[k]), wp[k], 0u);
+          v[k] = (mul_hi_u24(cur.wy0[r], h0 & 0xFFFFF0u) + mul_hi_u24(cur.wy1[r], h1 & 0xFFFFF0u) + 2u) >> 2;
+        }
+        *(uint32_t*)(dcol + (size_t)py * pstride) = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
       }
-      *(uint32_t*)(dcol + (size_t)py * pstride) = out;
     }
   }
 }
@@ -1492,8 +1522,13 @@ void launch_pyramid(const Plan& hp, const uint8_t* d_img, int istride, size_t if
     const LevelDesc& S = hp.lv[l - 1];
     const LevelDesc& L = hp.lv[l];
     const int nbx = (L.pstride + 255) / 256;
-    dim3 grid(nbx + 1, (L.prows + 15) / 16, nframes);
-    hipLaunchKernelGGL(k_pyr_resize, grid, blk, 0, s, d_pyr + S.pyr_off,
+    // rows per wave: as many 4-row steps (up to 4) as still leave the chip about two rounds of waves
+    int groups = 4;
+    while (groups > 1 && (long long)nbx * ((L.prows + 4 * groups - 1) / (4 * groups)) * nframes < 16384) groups >>= 1;
+    const int nbb = (4 * groups * L.n_bcols + 63) / 64;
+    dim3 grid(nbx + nbb, (L.prows + 4 * groups - 1) / (4 * groups), nframes);
+    auto kern = groups == 4 ? k_pyr_resize<4> : groups == 2 ? k_pyr_resize<2> : k_pyr_resize<1>;
+    hipLaunchKernelGGL(kern, grid, dim3(64), 0, s, d_pyr + S.pyr_off,
                        S.pstride, S.pyr_plane, d_pyr + L.pyr_off, L.pstride, L.prows, L.pyr_plane,
                        L.w + 2 * ORBX_EDGE, L.xtab, L.ytab, L.colrec, L.bcols,
                        L.n_bcols, nbx, f0);

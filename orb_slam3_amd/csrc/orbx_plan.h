@@ -19,7 +19,7 @@ namespace orbx {
 // Resize tap table entry, indexed by PADDED destination coordinate (the
 // REFLECT_101 border mapping is folded in): two source indices and the two
 // 11-bit fixed-point weights of cv::resize INTER_LINEAR.
-struct Tap {
+struct alignas(8) Tap {   // 8-byte aligned: wave-uniform entries are fetched with scalar loads
   uint16_t s0, s1;
   int16_t w0, w1;
 };
