@@ -191,7 +191,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=512, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=1024, help="frames per step per GPU")
     ap.add_argument("--no-match", action="store_true", help="skip the Hamming 2-NN and stereo legs")
     ap.add_argument("--distinct", type=int, default=32, help="distinct synthetic frames (tiled to the batch)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")

@@ -87,9 +87,14 @@ struct orbx_extractor {
   int device = 0;
   hipStream_t stream = nullptr;
   // side stream(s): independent stages run beside the latency-bound quadtree
-  static const int kLanes = 1;
+  // lane[0]: blur of the first half beside its quadtree; lane[1]: the second half of a large
+  // batch, one stage behind the first; lane[2]: blur of the second half
+  static const int kLanes = 3;
+  static const int kSplitMin = 128;   // frames per half below which a batch is not split
   hipStream_t lane[kLanes] = {};
   hipEvent_t evFork = nullptr, evJoin[kLanes] = {};
+  static const int kMaxParts = 2;     // more parts measured slower (shorter kernels, longer tails)
+  hipEvent_t evStart = nullptr, evForkB = nullptr, evPyr[kMaxParts] = {};
   hipError_t last_hip_error = hipSuccess;
 
   // plan for the current image size
@@ -467,18 +472,46 @@ int orbx_extractor::run(const uint8_t* d_images, int istride, size_t iframe, int
     // the chip idle; the blur only needs the pyramid, so it runs beside it on a second
     // stream.  (Starting the big levels' quadtrees earlier, beside the detection of the
     // small levels, measured slower: the two compete for LDS.)
-    hipStream_t q = lane[0];
-    orbx::launch_pyramid(hp, d_images, istride, iframe, d_pyr, 0, nframes, s);
-    orbx::launch_fast(hp, dp, d_pyr, d_cand, d_cellCount, 0, hp.nlevels, 0, nframes, s);
-    HIP_TRY(hipEventRecord(evFork, s));
-    HIP_TRY(hipStreamWaitEvent(q, evFork, 0));
-    orbx::launch_blur(hp, dp, d_pyr, d_blur, 0, nframes, q);
-    HIP_TRY(hipEventRecord(evJoin[0], q));
-    orbx::launch_octree(hp, dp, d_cand, d_cellCount, d_flatA, d_flatB, d_sel, d_selCount, d_octws, 0,
-                        hp.nlevels, 0, nframes, s);
-    orbx::launch_assemble(hp, dp, d_sel, d_selCount, lap0, lap1, d_kps, d_work, d_n, d_mono, 0, nframes, s);
-    HIP_TRY(hipStreamWaitEvent(s, evJoin[0], 0));
-    orbx::launch_describe(hp, dp, d_pyr, d_blur, d_work, d_n, d_kps, d_desc, 0, nframes, s);
+    // A large batch is cut in up to kMaxParts parts that alternate between two streams, each
+    // starting one stage behind the previous one, so that the latency-bound pyramid of a part
+    // overlaps the VALU-bound detection of the part before it, and its detection overlaps
+    // that part's quadtree and descriptors.
+    const int nparts = std::max(1, std::min(kMaxParts, nframes / kSplitMin));
+    auto part = [&](hipStream_t m, hipStream_t side, hipEvent_t fork, hipEvent_t join, int f0, int n,
+                    hipEvent_t pyrDone) -> int {
+      orbx::launch_pyramid(hp, d_images, istride, iframe, d_pyr, f0, n, m);
+      if (pyrDone) HIP_TRY(hipEventRecord(pyrDone, m));
+      orbx::launch_fast(hp, dp, d_pyr, d_cand, d_cellCount, 0, hp.nlevels, f0, n, m);
+      HIP_TRY(hipEventRecord(fork, m));
+      HIP_TRY(hipStreamWaitEvent(side, fork, 0));
+      orbx::launch_blur(hp, dp, d_pyr, d_blur, f0, n, side);
+      HIP_TRY(hipEventRecord(join, side));
+      orbx::launch_octree(hp, dp, d_cand, d_cellCount, d_flatA, d_flatB, d_sel, d_selCount, d_octws, 0,
+                          hp.nlevels, f0, n, m);
+      orbx::launch_assemble(hp, dp, d_sel, d_selCount, lap0, lap1, d_kps, d_work, d_n, d_mono, f0, n, m);
+      HIP_TRY(hipStreamWaitEvent(m, join, 0));
+      orbx::launch_describe(hp, dp, d_pyr, d_blur, d_work, d_n, d_kps, d_desc, f0, n, m);
+      return ORBX_OK;
+    };
+    if (nparts > 1) {
+      HIP_TRY(hipEventRecord(evStart, s));            // the second stream follows earlier work on s
+      HIP_TRY(hipStreamWaitEvent(lane[1], evStart, 0));
+    }
+    for (int k = 0, f0 = 0; k < nparts; ++k) {
+      const int n = (nframes - f0) / (nparts - k);
+      const bool odd = k & 1;
+      hipStream_t m = odd ? lane[1] : s;
+      // a part starts its pyramid when the previous part's pyramid is done
+      if (k > 0) HIP_TRY(hipStreamWaitEvent(m, evPyr[k - 1], 0));
+      const int st = part(m, odd ? lane[2] : lane[0], odd ? evForkB : evFork, odd ? evJoin[2] : evJoin[0],
+                          f0, n, k + 1 < nparts ? evPyr[k] : nullptr);
+      if (st != ORBX_OK) return st;
+      f0 += n;
+    }
+    if (nparts > 1) {
+      HIP_TRY(hipEventRecord(evJoin[1], lane[1]));
+      HIP_TRY(hipStreamWaitEvent(s, evJoin[1], 0));
+    }
   }
   evValid = prof;
   HIP_TRY(hipGetLastError());
@@ -526,7 +559,11 @@ int orbx_create(const orbx_params* p, orbx_extractor** out) {
   }
   for (int i = 0; i <= ORBX_NUM_STAGES; ++i)
     if (hipEventCreate(&ex->ev[i]) != hipSuccess) { orbx_destroy(ex); return ORBX_ERR_NO_DEVICE; }
-  bool ok = hipEventCreateWithFlags(&ex->evFork, hipEventDisableTiming) == hipSuccess;
+  bool ok = hipEventCreateWithFlags(&ex->evFork, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&ex->evStart, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&ex->evForkB, hipEventDisableTiming) == hipSuccess;
+  for (int k = 0; k < orbx_extractor::kMaxParts && ok; ++k)
+    ok = hipEventCreateWithFlags(&ex->evPyr[k], hipEventDisableTiming) == hipSuccess;
   for (int k = 0; k < orbx_extractor::kLanes && ok; ++k)
     ok = hipStreamCreateWithFlags(&ex->lane[k], hipStreamNonBlocking) == hipSuccess &&
          hipEventCreateWithFlags(&ex->evJoin[k], hipEventDisableTiming) == hipSuccess;
@@ -545,6 +582,9 @@ void orbx_destroy(orbx_extractor* ex) {
     if (ex->evJoin[k]) (void)hipEventDestroy(ex->evJoin[k]);
   }
   if (ex->evFork) (void)hipEventDestroy(ex->evFork);
+  if (ex->evStart) (void)hipEventDestroy(ex->evStart);
+  for (int k = 0; k < orbx_extractor::kMaxParts; ++k) if (ex->evPyr[k]) (void)hipEventDestroy(ex->evPyr[k]);
+  if (ex->evForkB) (void)hipEventDestroy(ex->evForkB);
   if (ex->evStereo) (void)hipEventDestroy(ex->evStereo);
   for (int i = 0; i < 2; ++i) if (ex->evIn[i]) (void)hipEventDestroy(ex->evIn[i]);
   if (ex->stream) (void)hipStreamDestroy(ex->stream);

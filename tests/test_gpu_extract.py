@@ -194,3 +194,20 @@ def test_device_resident_batch_matches_host_batch():
     for f in range(24):
         mono, k, desc = ex.download(f)
         assert mono == host[f][0] and np.array_equal(k, host[f][1]) and np.array_equal(desc, host[f][2])
+
+
+def test_split_batch_matches_single_frames():
+    """Batches of 256 frames and more are processed as two parts on two streams; every frame
+    must still equal its single-frame result (checked at the part boundary and the ends)."""
+    params = (1000, 1.2, 8, 20, 7)
+    distinct = [orbx.textured_frame(900 + i, 752, 480) for i in range(5)]
+    B = 261
+    frames = [distinct[i % 5] for i in range(B)]
+    ex = orbx.ORBextractor(*params, max_batch=B)
+    res = ex.extract_batch(frames, (0, 1000))
+    single = orbx.ORBextractor(*params)
+    ref = [single(d, None, (0, 1000)) for d in distinct]
+    for f in (0, 1, 129, 130, 131, 259, 260):
+        mono, k, d = res[f]
+        rmono, rk, rd = ref[f % 5]
+        assert mono == rmono and np.array_equal(k, rk) and np.array_equal(d, rd), f
