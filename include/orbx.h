@@ -211,6 +211,48 @@ int orbx_stereo_download(orbx_extractor* left, int frame, float* uright, float* 
 int orbx_stereo_match(orbx_extractor* left, orbx_extractor* right, float mbf, float mb,
                       float* uright, float* depth, int cap, int* n_out);
 
+/* ---- frame grid on device-resident extractions ------------------------------ */
+/* Pinhole camera with OpenCV's radial-tangential coefficients, as Frame holds
+ * them in mK and mDistCoef (k3 = 0 when the settings give four coefficients). */
+typedef struct orbx_pinhole {
+  float fx, fy, cx, cy;
+  float k1, k2, p1, p2, k3;
+} orbx_pinhole;
+
+/* cv::undistortPoints(src, dst, K, D, noArray(), K) as called at
+ * core/src/Frame.cc:787-788 and :814-815 (five fixed-point iterations in
+ * double).  xy / out_xy hold n (x, y) pairs.  Host. */
+int orbx_undistort_points(const orbx_pinhole* cam, const float* xy, int n, float* out_xy);
+/* Frame::ComputeImageBounds, core/src/Frame.cc:801-829:
+ * bounds = {mnMinX, mnMaxX, mnMinY, mnMaxY}; cam NULL or k1 == 0 gives the
+ * image rectangle.  Host. */
+int orbx_image_bounds(const orbx_pinhole* cam, int width, int height, float* bounds);
+
+/* Frame::UndistortKeyPoints (core/src/Frame.cc:771-799; a copy when cam is
+ * NULL or k1 == 0) followed by Frame::AssignFeaturesToGrid / PosInGrid
+ * (:432-459, :751-762) for frames [0, n_frames) of the last batched call on
+ * ex, on the keypoints where the extraction left them.  Asynchronous on the
+ * handle's stream.  The grid is a CSR over cells c = posX*48 + posY
+ * (mGrid[posX][posY]); a cell's keypoint indices are ascending, as push_back
+ * leaves them. */
+int orbx_frame_grid_batch_device(orbx_extractor* ex, int n_frames, const orbx_pinhole* cam,
+                                 const float* bounds);
+/* Device buffers of the last grid call: mvKeysUn [n_frames][cap] (28 B each),
+ * cell starts int32 [n_frames][64*48+1], cell entries int32 [n_frames][cap]. */
+int orbx_frame_grid_results_device(orbx_extractor* ex, orbx_keypoint** d_kps_un,
+                                   int32_t** d_cell_start, int32_t** d_cell_entries, int* cap);
+/* Copy frame f to the host: kps_un holds cap keypoints, cell_start 64*48+1
+ * entries, cell_entries cap entries; any pointer may be NULL. */
+int orbx_frame_grid_download(orbx_extractor* ex, int frame, orbx_keypoint* kps_un,
+                             int32_t* cell_start, int32_t* cell_entries, int cap, int* n_out);
+/* Frame::GetFeaturesInArea, core/src/Frame.cc:682-749, for n_queries windows
+ * on one frame of the last grid call.  queries holds 5 floats per window: x, y,
+ * r, minLevel, maxLevel.  counts[q] = number of keypoints found; the first
+ * per_query_cap of them go to indices[q*per_query_cap ...] in the reference's
+ * order.  Host pointers; blocks until done. */
+int orbx_features_in_area(orbx_extractor* ex, int frame, const float* queries, int n_queries,
+                          int32_t* indices, int per_query_cap, int32_t* counts);
+
 /* ---- synthetic input ------------------------------------------------------- */
 /* Deterministic textured test frame (PCG32-seeded rectangles + noise + 3x3
  * box blur), written to dst (height rows of stride bytes).  Host only. */

@@ -884,4 +884,121 @@ int orc_stereo_match(orc_extractor* hl, orc_extractor* hr, const void* kpsL28, c
   return 0;
 }
 
+// ---- frame grid (the consumer right after extraction) -------------------------------------
+// cv::undistortPoints(src, dst, K, D, noArray(), P = K) as Frame::UndistortKeyPoints and
+// Frame::ComputeImageBounds call it (core/src/Frame.cc:787-788, 814-815): OpenCV's iterative
+// inverse of the radial-tangential model, 5 fixed-point iterations (the public entry point
+// uses TermCriteria(MAX_ITER, 5, 0.01)), all in double, result stored as float.
+// cam = fx, fy, cx, cy, k1, k2, p1, p2, k3.  xy / out hold n (x, y) pairs.
+void orc_undistort_points(const float* cam, const float* xy, int n, float* out) {
+  const double fx = cam[0], fy = cam[1], cx = cam[2], cy = cam[3];
+  const double k1 = cam[4], k2 = cam[5], p1 = cam[6], p2 = cam[7], k3 = cam[8];
+  const double ifx = 1. / fx, ify = 1. / fy;
+  for (int i = 0; i < n; ++i) {
+    const double u = xy[2 * i], v = xy[2 * i + 1];
+    double x = (u - cx) * ifx, y = (v - cy) * ify;
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; ++j) {
+      const double r2 = x * x + y * y;
+      const double icdist = (1 + ((0 * r2 + 0) * r2 + 0) * r2) / (1 + ((k3 * r2 + k2) * r2 + k1) * r2);
+      if (icdist < 0) { x = (u - cx) * ifx; y = (v - cy) * ify; break; }
+      const double deltaX = 2 * p1 * x * y + p2 * (r2 + 2 * x * x);
+      const double deltaY = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y;
+      x = (x0 - deltaX) * icdist;
+      y = (y0 - deltaY) * icdist;
+    }
+    // new projection P = K, rectification = identity
+    const double xx = fx * x + 0 * y + cx, yy = 0 * x + fy * y + cy, ww = 1. / (0 * x + 0 * y + 1);
+    out[2 * i] = (float)(xx * ww);
+    out[2 * i + 1] = (float)(yy * ww);
+  }
+}
+
+// Frame::ComputeImageBounds, core/src/Frame.cc:801-829: bounds = mnMinX, mnMaxX, mnMinY, mnMaxY.
+void orc_image_bounds(const float* cam, int cols, int rows, float* bounds) {
+  if (cam && cam[4] != 0.0f) {
+    const float c[8] = {0.f, 0.f, (float)cols, 0.f, 0.f, (float)rows, (float)cols, (float)rows};
+    float m[8];
+    orc_undistort_points(cam, c, 4, m);
+    bounds[0] = std::min(m[0], m[4]);
+    bounds[1] = std::max(m[2], m[6]);
+    bounds[2] = std::min(m[1], m[3]);
+    bounds[3] = std::max(m[5], m[7]);
+  } else {
+    bounds[0] = 0.0f; bounds[1] = (float)cols; bounds[2] = 0.0f; bounds[3] = (float)rows;
+  }
+}
+
+// Frame::UndistortKeyPoints (:771-799) + Frame::AssignFeaturesToGrid / PosInGrid (:432-459,
+// :751-762) for the monocular / rectified case (Nleft == -1).  kpsUn receives the keypoints
+// with undistorted coordinates (a copy when k1 == 0, :772-775).  The grid is returned as a
+// CSR over cells c = posX * 48 + posY (mGrid[posX][posY]): cellStart has 64*48+1 entries and
+// entries lists keypoint indices in push_back order (ascending).
+void orc_frame_grid(const float* cam, const float* bounds, const void* kps28, int n, void* kpsUn28,
+                    int* cellStart, int* entries) {
+  const KeyPoint* K = (const KeyPoint*)kps28;
+  KeyPoint* U = (KeyPoint*)kpsUn28;
+  for (int i = 0; i < n; ++i) U[i] = K[i];
+  if (cam && cam[4] != 0.0f && n > 0) {
+    std::vector<float> xy(2 * (size_t)n), o(2 * (size_t)n);
+    for (int i = 0; i < n; ++i) { xy[2 * i] = K[i].x; xy[2 * i + 1] = K[i].y; }
+    orc_undistort_points(cam, xy.data(), n, o.data());
+    for (int i = 0; i < n; ++i) { U[i].x = o[2 * i]; U[i].y = o[2 * i + 1]; }
+  }
+  const int COLS = 64, ROWS = 48;
+  const float invW = (float)COLS / (bounds[1] - bounds[0]);   // Frame.cc:193-196
+  const float invH = (float)ROWS / (bounds[3] - bounds[2]);
+  std::vector<std::vector<int>> grid(COLS * ROWS);
+  for (int i = 0; i < n; ++i) {
+    const int posX = (int)std::round((U[i].x - bounds[0]) * invW);
+    const int posY = (int)std::round((U[i].y - bounds[2]) * invH);
+    if (posX < 0 || posX >= COLS || posY < 0 || posY >= ROWS) continue;
+    grid[posX * ROWS + posY].push_back(i);
+  }
+  int run = 0;
+  for (int c = 0; c < COLS * ROWS; ++c) {
+    cellStart[c] = run;
+    for (int i : grid[c]) entries[run++] = i;
+  }
+  cellStart[COLS * ROWS] = run;
+}
+
+// Frame::GetFeaturesInArea, core/src/Frame.cc:682-749 (left / monocular grid), on the CSR
+// above.  Returns the number of indices found; the first cap of them are written to out in
+// the reference's order (ix ascending, iy ascending, cell order).
+int orc_features_in_area(const float* bounds, const void* kpsUn28, const int* cellStart,
+                         const int* entries, float x, float y, float r, int minLevel, int maxLevel,
+                         int* out, int cap) {
+  const KeyPoint* U = (const KeyPoint*)kpsUn28;
+  const int COLS = 64, ROWS = 48;
+  const float invW = (float)COLS / (bounds[1] - bounds[0]);
+  const float invH = (float)ROWS / (bounds[3] - bounds[2]);
+  const float factorX = r, factorY = r;
+  const int nMinCellX = std::max(0, (int)std::floor((x - bounds[0] - factorX) * invW));
+  if (nMinCellX >= COLS) return 0;
+  const int nMaxCellX = std::min(COLS - 1, (int)std::ceil((x - bounds[0] + factorX) * invW));
+  if (nMaxCellX < 0) return 0;
+  const int nMinCellY = std::max(0, (int)std::floor((y - bounds[2] - factorY) * invH));
+  if (nMinCellY >= ROWS) return 0;
+  const int nMaxCellY = std::min(ROWS - 1, (int)std::ceil((y - bounds[2] + factorY) * invH));
+  if (nMaxCellY < 0) return 0;
+  const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+  int found = 0;
+  for (int ix = nMinCellX; ix <= nMaxCellX; ++ix)
+    for (int iy = nMinCellY; iy <= nMaxCellY; ++iy)
+      for (int e = cellStart[ix * ROWS + iy]; e < cellStart[ix * ROWS + iy + 1]; ++e) {
+        const KeyPoint& kp = U[entries[e]];
+        if (bCheckLevels) {
+          if (kp.octave < minLevel) continue;
+          if (maxLevel >= 0 && kp.octave > maxLevel) continue;
+        }
+        const float distx = kp.x - x, disty = kp.y - y;
+        if (std::fabs(distx) < factorX && std::fabs(disty) < factorY) {
+          if (found < cap) out[found] = entries[e];
+          ++found;
+        }
+      }
+  return found;
+}
+
 }  // extern "C"

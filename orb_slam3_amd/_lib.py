@@ -34,6 +34,10 @@ class OrbxParams(C.Structure):
                 ("max_batch", C.c_int32)]
 
 
+class OrbxPinhole(C.Structure):
+    _fields_ = [(k, C.c_float) for k in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "k3")]
+
+
 class OrbxError(RuntimeError):
     def __init__(self, status, what=""):
         self.status = status
@@ -83,6 +87,12 @@ SIGNATURES = {
     "orbx_stereo_results_device": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), _i32p]),
     "orbx_stereo_download": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int, _i32p]),
     "orbx_stereo_match": (C.c_int, [_P, _P, C.c_float, C.c_float, _P, _P, C.c_int, _i32p]),
+    "orbx_undistort_points": (C.c_int, [C.POINTER(OrbxPinhole), _f32p, C.c_int, _f32p]),
+    "orbx_image_bounds": (C.c_int, [C.POINTER(OrbxPinhole), C.c_int, C.c_int, _f32p]),
+    "orbx_frame_grid_batch_device": (C.c_int, [_P, C.c_int, C.POINTER(OrbxPinhole), _f32p]),
+    "orbx_frame_grid_results_device": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _i32p]),
+    "orbx_frame_grid_download": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int, _i32p]),
+    "orbx_features_in_area": (C.c_int, [_P, C.c_int, _f32p, C.c_int, _P, C.c_int, _P]),
     "orbx_synth_frame": (C.c_int, [C.c_uint32, C.c_int, C.c_int, C.c_int, _P]),
 }
 

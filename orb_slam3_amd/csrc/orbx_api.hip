@@ -38,6 +38,13 @@ void launch_stereo(const Plan& hp, const Plan* dp, const uint8_t* pyrL, const ui
                    float mb, int* rowStart, int* entries, int* bandIdx, int* bandDist, int* sadDist,
                    float* uRight, float* depth, int nframes, hipStream_t s);
 int stereo_entries_per_keypoint(const Plan& hp);
+size_t frame_grid_lds_bytes(int cap);
+void launch_frame_grid(const float* d_kps, const int* d_n, int cap, const orbx_pinhole& cam, int distorted,
+                       const float* bounds, float* d_kpsUn, int* d_cellStart, int* d_entries,
+                       int nframes, hipStream_t s);
+void launch_features_in_area(const float* d_kpsUn, int cap, const int* d_cellStart, const int* d_entries,
+                             int frame, const float* bounds, const float* d_queries, int nq, int* d_out,
+                             int percap, int* d_counts, hipStream_t s);
 int launch_debug_sort(uint64_t* d_data, int n, hipStream_t s);
 }  // namespace orbx
 
@@ -129,6 +136,12 @@ struct orbx_extractor {
   float* d_stURight = nullptr;
   float* d_stDepth = nullptr;
   int stereoFrames = 0;
+  // frame grid of the last grid call (undistorted keypoints + 64x48 cell CSR)
+  float* d_kpsUn = nullptr;
+  int* d_cellStart = nullptr;
+  int* d_cellEntries = nullptr;
+  int gridFrames = 0;
+  float gridBounds[4] = {0, 0, 0, 0};
   hipEvent_t evStereo = nullptr;
 
   // pinned host staging
@@ -196,6 +209,9 @@ void orbx_extractor::freePlan() {
   (void)hipStreamSynchronize(stream);
   for (void* t : d_taps) (void)hipFree(t);
   d_taps.clear();
+  void* gbufs[] = {d_kpsUn, d_cellStart, d_cellEntries};
+  for (void* b : gbufs) if (b) (void)hipFree(b);
+  d_kpsUn = nullptr; d_cellStart = d_cellEntries = nullptr; gridFrames = 0;
   void* sbufs[] = {d_stRowStart, d_stEntries, d_stBandIdx, d_stBandDist, d_stSad, d_stURight, d_stDepth};
   for (void* b : sbufs) if (b) (void)hipFree(b);
   d_stRowStart = d_stEntries = nullptr; stRightCap = 0;
@@ -832,6 +848,100 @@ int orbx_stereo_match(orbx_extractor* left, orbx_extractor* right, float mbf, fl
   int st = orbx_stereo_match_batch_device(left, right, 1, mbf, mb);
   if (st != ORBX_OK) return st;
   return orbx_stereo_download(left, 0, uright, depth, nullptr, cap, n_out);
+}
+
+// ---- frame grid on a device-resident extraction -----------------------------------------------
+#define ORBX_GRID_CELLS (64 * 48)
+
+int orbx_frame_grid_batch_device(orbx_extractor* ex, int n_frames, const orbx_pinhole* cam,
+                                 const float* bounds) {
+  if (!ex || !ex->planned || n_frames <= 0 || !bounds) return ORBX_ERR_BAD_ARG;
+  if (!(bounds[1] > bounds[0]) || !(bounds[3] > bounds[2])) return ORBX_ERR_BAD_ARG;
+  if (n_frames > ex->lastFrames) return ORBX_ERR_BATCH;
+  if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  auto& last_hip_error = ex->last_hip_error;
+  const int cap = ex->hp.kp_cap;
+  if (cap >= 0xFFFF || orbx::frame_grid_lds_bytes(cap) > 64 * 1024) return ORBX_ERR_UNSUPPORTED;
+  if (!ex->d_kpsUn) {
+    const size_t B = (size_t)ex->prm.max_batch;
+    HIP_TRY(hipMalloc((void**)&ex->d_kpsUn, B * cap * 28));
+    HIP_TRY(hipMalloc((void**)&ex->d_cellStart, B * (ORBX_GRID_CELLS + 1) * 4));
+    HIP_TRY(hipMalloc((void**)&ex->d_cellEntries, B * cap * 4));
+  }
+  orbx_pinhole c;
+  std::memset(&c, 0, sizeof(c));
+  if (cam) c = *cam;
+  const int distorted = cam && cam->k1 != 0.0f;      // Frame.cc:772
+  if (distorted && (!(c.fx != 0.f) || !(c.fy != 0.f))) return ORBX_ERR_BAD_ARG;
+  orbx::launch_frame_grid(ex->d_kps, ex->d_n, cap, c, distorted, bounds, ex->d_kpsUn, ex->d_cellStart,
+                          ex->d_cellEntries, n_frames, ex->stream);
+  HIP_TRY(hipGetLastError());
+  ex->gridFrames = n_frames;
+  std::memcpy(ex->gridBounds, bounds, sizeof(ex->gridBounds));
+  return ORBX_OK;
+}
+
+int orbx_frame_grid_results_device(orbx_extractor* ex, orbx_keypoint** d_kps_un, int32_t** d_cell_start,
+                                   int32_t** d_cell_entries, int* cap) {
+  if (!ex || !ex->planned || !ex->d_kpsUn) return ORBX_ERR_BAD_ARG;
+  if (d_kps_un) *d_kps_un = (orbx_keypoint*)ex->d_kpsUn;
+  if (d_cell_start) *d_cell_start = ex->d_cellStart;
+  if (d_cell_entries) *d_cell_entries = ex->d_cellEntries;
+  if (cap) *cap = ex->hp.kp_cap;
+  return ORBX_OK;
+}
+
+int orbx_frame_grid_download(orbx_extractor* ex, int frame, orbx_keypoint* kps_un, int32_t* cell_start,
+                             int32_t* cell_entries, int cap, int* n_out) {
+  if (!ex || !ex->planned || !ex->d_kpsUn || frame < 0 || frame >= ex->gridFrames) return ORBX_ERR_BAD_ARG;
+  if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  auto& last_hip_error = ex->last_hip_error;
+  hipStream_t s = ex->stream;
+  int n = 0;
+  HIP_TRY(hipMemcpyAsync(&n, ex->d_n + frame, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (n_out) *n_out = n;
+  if (n > cap) return ORBX_ERR_CAPACITY;
+  const size_t base = (size_t)frame * ex->hp.kp_cap;
+  if (kps_un && n > 0) HIP_TRY(hipMemcpyAsync(kps_un, ex->d_kpsUn + base * 7, (size_t)n * 28, hipMemcpyDeviceToHost, s));
+  if (cell_start)
+    HIP_TRY(hipMemcpyAsync(cell_start, ex->d_cellStart + (size_t)frame * (ORBX_GRID_CELLS + 1),
+                           (size_t)(ORBX_GRID_CELLS + 1) * 4, hipMemcpyDeviceToHost, s));
+  if (cell_entries && n > 0)
+    HIP_TRY(hipMemcpyAsync(cell_entries, ex->d_cellEntries + base, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return ORBX_OK;
+}
+
+int orbx_features_in_area(orbx_extractor* ex, int frame, const float* queries, int n_queries,
+                          int32_t* indices, int per_query_cap, int32_t* counts) {
+  if (!ex || !ex->planned || !ex->d_kpsUn || frame < 0 || frame >= ex->gridFrames || n_queries < 0 ||
+      per_query_cap < 0 || (n_queries > 0 && (!queries || !counts || (per_query_cap > 0 && !indices))))
+    return ORBX_ERR_BAD_ARG;
+  if (n_queries == 0) return ORBX_OK;
+  if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  auto& last_hip_error = ex->last_hip_error;
+  hipStream_t s = ex->stream;
+  float* dq = nullptr;
+  int *dout = nullptr, *dcnt = nullptr;
+  hipError_t e = hipMallocAsync((void**)&dq, (size_t)n_queries * 20, s);
+  if (e == hipSuccess) e = hipMallocAsync((void**)&dout, (size_t)n_queries * std::max(per_query_cap, 1) * 4, s);
+  if (e == hipSuccess) e = hipMallocAsync((void**)&dcnt, (size_t)n_queries * 4, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(dq, queries, (size_t)n_queries * 20, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) {
+    orbx::launch_features_in_area(ex->d_kpsUn, ex->hp.kp_cap, ex->d_cellStart, ex->d_cellEntries, frame,
+                                  ex->gridBounds, dq, n_queries, dout, per_query_cap, dcnt, s);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(counts, dcnt, (size_t)n_queries * 4, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess && per_query_cap > 0)
+    e = hipMemcpyAsync(indices, dout, (size_t)n_queries * per_query_cap * 4, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (dq) (void)hipFreeAsync(dq, s);
+  if (dout) (void)hipFreeAsync(dout, s);
+  if (dcnt) (void)hipFreeAsync(dcnt, s);
+  if (e != hipSuccess) { last_hip_error = e; return ORBX_ERR_HIP; }
+  return ORBX_OK;
 }
 
 int orbx_level_dims(orbx_extractor* ex, int level, int* width, int* height, int* stride) {

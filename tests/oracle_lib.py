@@ -45,6 +45,12 @@ def lib():
         L.orc_stereo_match.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                        C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
                                        C.c_void_p]
+        L.orc_undistort_points.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_image_bounds.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.orc_frame_grid.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                     C.c_void_p]
+        L.orc_features_in_area.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                                           C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int]
         _lib = L
     return _lib
 
@@ -206,3 +212,43 @@ def stereo_match(ex_l, ex_r, kl, dl, kr, dr, mbf, mb):
                                 _p(ur), _p(dp), _p(sad))
     assert st == 0
     return ur[:n], dp[:n], sad[:n]
+
+
+def _cam(cam):
+    return None if cam is None else np.ascontiguousarray(cam, np.float32)
+
+
+def undistort_points(cam, xy):
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    out = np.empty_like(xy)
+    lib().orc_undistort_points(_p(_cam(cam)), _p(xy), len(xy), _p(out))
+    return out
+
+
+def image_bounds(cam, cols, rows):
+    b = np.zeros(4, np.float32)
+    c = _cam(cam)
+    lib().orc_image_bounds(_p(c) if c is not None else None, cols, rows, _p(b))
+    return b
+
+
+def frame_grid(cam, bounds, kps):
+    kps = np.ascontiguousarray(kps, KP)
+    un = np.zeros(max(len(kps), 1), KP)
+    cs = np.zeros(64 * 48 + 1, np.int32)
+    ent = np.zeros(max(len(kps), 1), np.int32)
+    c = _cam(cam)
+    b = np.ascontiguousarray(bounds, np.float32)
+    lib().orc_frame_grid(_p(c) if c is not None else None, _p(b), _p(kps), len(kps), _p(un), _p(cs), _p(ent))
+    return un[:len(kps)], cs, ent[:cs[-1]]
+
+
+def features_in_area(bounds, kps_un, cs, ent, x, y, r, min_level, max_level, cap=64):
+    kps_un = np.ascontiguousarray(kps_un, KP)
+    ent = np.ascontiguousarray(ent, np.int32)
+    if len(ent) == 0:
+        ent = np.zeros(1, np.int32)
+    b = np.ascontiguousarray(bounds, np.float32)
+    out = np.full(cap, -1, np.int32)
+    n = lib().orc_features_in_area(_p(b), _p(kps_un), _p(cs), _p(ent), x, y, r, min_level, max_level, _p(out), cap)
+    return n, out

@@ -243,3 +243,59 @@ def test_stereo_match_constant_disparity(oracle):
     removed = (sad >= 0) & ~ok
     if removed.any():
         assert sad[removed].min() >= sad[ok].max()
+
+
+EUROC_CAM = (458.654, 457.296, 367.215, 248.375, -0.28340811, 0.07395907, 0.00019359, 1.76187114e-05, 0.0)
+
+
+def _distort(cam, xn, yn):
+    """Forward radial-tangential model in float64 (what undistortPoints inverts)."""
+    fx, fy, cx, cy, k1, k2, p1, p2, k3 = cam
+    r2 = xn * xn + yn * yn
+    rad = 1 + k1 * r2 + k2 * r2 * r2 + k3 * r2 ** 3
+    xd = xn * rad + 2 * p1 * xn * yn + p2 * (r2 + 2 * xn * xn)
+    yd = yn * rad + p1 * (r2 + 2 * yn * yn) + 2 * p2 * xn * yn
+    return xd * fx + cx, yd * fy + cy
+
+
+def test_undistort_points_inverts_the_distortion_model(oracle):
+    """Distort a lattice of ideal pixels with the forward model, undistort with the restated
+    cv::undistortPoints: the ideal pixels come back within the residual of 5 iterations."""
+    fx, fy, cx, cy = EUROC_CAM[:4]
+    gx, gy = np.meshgrid(np.linspace(20, 730, 15), np.linspace(20, 460, 11))
+    ideal = np.stack([gx.ravel(), gy.ravel()], 1)
+    ud, vd = _distort(EUROC_CAM, (ideal[:, 0] - cx) / fx, (ideal[:, 1] - cy) / fy)
+    back = oracle.undistort_points(EUROC_CAM, np.stack([ud, vd], 1).astype(np.float32))
+    err = np.abs(back - ideal).max(axis=1)
+    assert err.max() < 0.5                       # five iterations leave a few tenths at the corners
+    centre = np.hypot(ideal[:, 0] - cx, ideal[:, 1] - cy) < 150
+    assert err[centre].max() < 0.01
+    # zero coefficients: identity up to float rounding
+    same = oracle.undistort_points(EUROC_CAM[:4] + (0, 0, 0, 0, 0), ideal.astype(np.float32))
+    assert np.abs(same - ideal).max() < 1e-3
+
+
+def test_image_bounds_and_grid_invariants(oracle):
+    b = oracle.image_bounds(EUROC_CAM, 752, 480)
+    assert b[0] < 0 and b[2] < 0 and b[1] > 752 and b[3] > 480      # barrel distortion widens the frame
+    assert np.array_equal(oracle.image_bounds(None, 752, 480), np.array([0, 752, 0, 480], np.float32))
+    rng = np.random.default_rng(4)
+    k = np.zeros(1500, oracle.KP)
+    k["x"] = rng.uniform(0, 752, 1500).astype(np.float32)
+    k["y"] = rng.uniform(0, 480, 1500).astype(np.float32)
+    k["octave"] = rng.integers(0, 8, 1500)
+    un, cs, ent = oracle.frame_grid(EUROC_CAM, b, k)
+    assert cs[0] == 0 and (np.diff(cs) >= 0).all() and cs[-1] == len(ent) <= 1500
+    assert len(set(ent.tolist())) == len(ent)
+    for c in np.nonzero(np.diff(cs) > 1)[0][:50]:
+        assert (np.diff(ent[cs[c]:cs[c + 1]]) > 0).all()           # push_back order
+    inv_w, inv_h = np.float32(64) / (b[1] - b[0]), np.float32(48) / (b[3] - b[2])
+    for c in np.nonzero(np.diff(cs) > 0)[0][:200]:
+        i = ent[cs[c]]
+        px = int(np.floor((un["x"][i] - b[0]) * inv_w + np.float32(0.5)))
+        assert abs(px - c // 48) <= 1
+    # a window query returns exactly the brute-force set
+    n, out = oracle.features_in_area(b, un, cs, ent, 300.0, 200.0, 40.0, 1, 5, cap=256)
+    brute = [i for i in range(1500) if abs(un["x"][i] - 300) < 40 and abs(un["y"][i] - 200) < 40
+             and 1 <= un["octave"][i] <= 5 and i in set(ent.tolist())]
+    assert n == len(brute) and sorted(out[:n].tolist()) == brute
