@@ -377,12 +377,20 @@ int orbx_extractor::ensurePlan(int W, int H) {
     for (int c = 0; c < ncol; ++c) {
       ColRec r;
       std::memset(&r, 0, sizeof(r));
-      bool ok = 4 * c + 3 < pw;
+      // pixels of the row's last dword that lie beyond the padded width repeat the last real
+      // pixel's taps and are masked to zero when stored
+      const int nvalid = std::min(4, pw - 4 * c);
+      bool ok = nvalid >= 1;
       if (ok) {
-        const int sxa = tx[4 * c].s0;
+        auto tapOf = [&](int k) -> const Tap& { return tx[std::min(4 * c + k, pw - 1)]; };
+        // lowest left tap of the four pixels: in the reflected left/right border the pixels
+        // run backwards through the source, which the per-pixel deltas express just as well
+        int sxa = tapOf(0).s0;
+        for (int k = 1; k < 4; ++k) sxa = std::min(sxa, (int)tapOf(k).s0);
         r.sxa = (uint16_t)sxa;
+        r.nvalid = (uint16_t)nvalid;
         for (int k = 0; k < 4 && ok; ++k) {
-          const Tap& t = tx[4 * c + k];
+          const Tap& t = tapOf(k);
           const int d = (int)t.s0 - sxa;
           ok = d >= 0 && d <= 6 && (t.s1 == t.s0 + 1 || (t.s1 == t.s0 && t.w1 == 0)) &&
                t.w0 + t.w1 == 2048 && t.w1 >= 0;

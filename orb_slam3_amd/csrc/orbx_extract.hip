@@ -146,13 +146,14 @@ __global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t* __restrict__ 
 // The tap tables are indexed by padded destination coordinates, so border
 // pixels are produced by the same code as interior ones.
 //
-// One wave per workgroup.  A main wave owns 64 destination dword columns (256
-// pixels) and 4 * groups rows, walked 4 rows at a time with the next step's
-// source rows already in flight: the stage is bound by memory latency, not by
-// bytes or arithmetic, so every wave keeps two steps of independent loads
-// outstanding and reuses its column record for all rows.  Columns in the
-// reflected border or at the clamped right edge go through the per-pixel tap
-// table in separate border waves, so that no wave mixes the two code paths.
+// Workgroups are few and fat: an empty launch of this stage's former one-wave
+// workgroups already cost half of the stage (the dispatcher hands out about two
+// workgroups per nanosecond).  A main wave owns 64 destination dword columns
+// (256 pixels) and 4 * GROUPS rows, walked 4 rows at a time with the next
+// step's source rows already in flight; four waves form a workgroup.  Columns
+// in the reflected border or at the clamped right edge go through the
+// per-pixel tap table in separate border workgroups, so that no wave mixes the
+// two code paths.
 // ---------------------------------------------------------------------------
 struct ResizeRows {
   uint32_t a[4][3], b[4][3];   // upper / lower source row of 4 destination rows
@@ -175,7 +176,7 @@ __device__ __forceinline__ void resize_fetch(ResizeRows& R, const uint8_t* base,
 }
 
 template <int GROUPS>
-__global__ __launch_bounds__(64) void k_pyr_resize(const uint8_t* __restrict__ src, int sstride,
+__global__ __launch_bounds__(256) void k_pyr_resize(const uint8_t* __restrict__ src, int sstride,
                                                    size_t splane, uint8_t* __restrict__ dst,
                                                    int pstride, int prows, size_t dplane, int pw,
                                                    const Tap* __restrict__ xtab,
@@ -184,33 +185,36 @@ __global__ __launch_bounds__(64) void k_pyr_resize(const uint8_t* __restrict__ s
                                                    const uint16_t* __restrict__ bcols, int nbc, int nbx,
                                                    int f0) {
   const int lane = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
   const int f = blockIdx.z + f0;
   constexpr int rowsPerWave = 4 * GROUPS;
+  constexpr int rowsPerBlock = 4 * rowsPerWave;
   if ((int)blockIdx.x >= nbx) {
-    // border wave: one lane per (row, border dword); taps straight from the tables,
+    // border block: one lane per (row, border dword); taps straight from the tables,
     // source bytes straight from the (cache-resident) source plane
     const uint8_t* roi = src + (size_t)f * splane + (size_t)ORBX_EDGE * sstride + ORBX_EDGE;
-    const int t = ((int)blockIdx.x - nbx) * 64 + lane;
-    if (t >= rowsPerWave * nbc) return;
-    const int r = (int)(((float)t + 0.5f) * (1.0f / (float)nbc));
-    const int py = blockIdx.y * rowsPerWave + r;
-    if (py >= prows) return;
-    const int c = bcols[t - r * nbc];
-    const Tap ty = ytab[py];
-    const uint8_t* r0 = roi + (size_t)ty.s0 * sstride;
-    const uint8_t* r1 = roi + (size_t)ty.s1 * sstride;
-    uint32_t out = 0;
+    const float rnb = 1.0f / (float)nbc;
+    for (int t = wave * 64 + lane; t < rowsPerBlock * nbc; t += 256) {
+      const int r = (int)(((float)t + 0.5f) * rnb);
+      const int py = blockIdx.y * rowsPerBlock + r;
+      if (py >= prows) break;
+      const int c = bcols[t - r * nbc];
+      const Tap ty = ytab[py];
+      const uint8_t* r0 = roi + (size_t)ty.s0 * sstride;
+      const uint8_t* r1 = roi + (size_t)ty.s1 * sstride;
+      uint32_t out = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int px = 4 * c + k;
-      const Tap tx = xtab[min(px, pw - 1)];
-      const uint32_t h0 = __umul24(r0[tx.s0], (uint32_t)(int)tx.w0) + __umul24(r0[tx.s1], (uint32_t)(int)tx.w1);
-      const uint32_t h1 = __umul24(r1[tx.s0], (uint32_t)(int)tx.w0) + __umul24(r1[tx.s1], (uint32_t)(int)tx.w1);
-      const uint32_t v = ((__umul24((uint32_t)(int)ty.w0, h0 >> 4) >> 16) +
-                          (__umul24((uint32_t)(int)ty.w1, h1 >> 4) >> 16) + 2u) >> 2;
-      out |= (px < pw ? (v & 0xFFu) : 0u) << (8 * k);
+      for (int k = 0; k < 4; ++k) {
+        const int px = 4 * c + k;
+        const Tap tx = xtab[min(px, pw - 1)];
+        const uint32_t h0 = __umul24(r0[tx.s0], (uint32_t)(int)tx.w0) + __umul24(r0[tx.s1], (uint32_t)(int)tx.w1);
+        const uint32_t h1 = __umul24(r1[tx.s0], (uint32_t)(int)tx.w0) + __umul24(r1[tx.s1], (uint32_t)(int)tx.w1);
+        const uint32_t v = ((__umul24((uint32_t)(int)ty.w0, h0 >> 4) >> 16) +
+                            (__umul24((uint32_t)(int)ty.w1, h1 >> 4) >> 16) + 2u) >> 2;
+        out |= (px < pw ? (v & 0xFFu) : 0u) << (8 * k);
+      }
+      *(uint32_t*)(dst + (size_t)f * dplane + (size_t)py * pstride + 4 * c) = out;
     }
-    *(uint32_t*)(dst + (size_t)f * dplane + (size_t)py * pstride + 4 * c) = out;
     return;
   }
   // main waves: one lane = one destination dword column (4 pixels).  The 8 source bytes that
@@ -230,8 +234,10 @@ __global__ __launch_bounds__(64) void k_pyr_resize(const uint8_t* __restrict__ s
     sel[k] = 0x0c000c00u | d | ((d + 1u) << 16);
     wp[k] = (2048u - cr.w1[k]) | ((uint32_t)cr.w1[k] << 16);  // (left, right) weights
   }
+  const uint32_t keep = cr.nvalid >= 4 ? 0xFFFFFFFFu : ((1u << (8 * cr.nvalid)) - 1u);
   uint8_t* dcol = dst + (size_t)f * dplane + 4 * c;
-  const int pyBase = blockIdx.y * rowsPerWave;
+  const int pyBase = (blockIdx.y * 4 + wave) * rowsPerWave;
+  if (pyBase >= prows) return;
   // the row taps of all steps first: wave-uniform, read before any store so that they can
   // come through the scalar cache
   Tap tys[rowsPerWave];
@@ -260,7 +266,7 @@ __global__ __launch_bounds__(64) void k_pyr_resize(const uint8_t* __restrict__ s
           const uint32_t h1 = udot2(__builtin_amdgcn_perm(bhi, blo, sel[k]), wp[k], 0u);
           v[k] = (mul_hi_u24(cur.wy0[r], h0 & 0xFFFFF0u) + mul_hi_u24(cur.wy1[r], h1 & 0xFFFFF0u) + 2u) >> 2;
         }
-        *(uint32_t*)(dcol + (size_t)py * pstride) = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+        *(uint32_t*)(dcol + (size_t)py * pstride) = (v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24)) & keep;
       }
     }
   }
@@ -1525,10 +1531,9 @@ void launch_pyramid(const Plan& hp, const uint8_t* d_img, int istride, size_t if
     // rows per wave: as many 4-row steps (up to 4) as still leave the chip about two rounds of waves
     int groups = 4;
     while (groups > 1 && (long long)nbx * ((L.prows + 4 * groups - 1) / (4 * groups)) * nframes < 16384) groups >>= 1;
-    const int nbb = (4 * groups * L.n_bcols + 63) / 64;
-    dim3 grid(nbx + nbb, (L.prows + 4 * groups - 1) / (4 * groups), nframes);
+    dim3 grid(nbx + (L.n_bcols > 0 ? 1 : 0), (L.prows + 16 * groups - 1) / (16 * groups), nframes);
     auto kern = groups == 4 ? k_pyr_resize<4> : groups == 2 ? k_pyr_resize<2> : k_pyr_resize<1>;
-    hipLaunchKernelGGL(kern, grid, dim3(64), 0, s, d_pyr + S.pyr_off,
+    hipLaunchKernelGGL(kern, grid, blk, 0, s, d_pyr + S.pyr_off,
                        S.pstride, S.pyr_plane, d_pyr + L.pyr_off, L.pstride, L.prows, L.pyr_plane,
                        L.w + 2 * ORBX_EDGE, L.xtab, L.ytab, L.colrec, L.bcols,
                        L.n_bcols, nbx, f0);

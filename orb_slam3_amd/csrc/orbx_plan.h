@@ -30,7 +30,8 @@ struct ColRec {
   uint16_t sxa;      // source x of pixel 0's left tap
   uint16_t deltas;   // 3 bits per pixel: left tap - sxa (0..6); bit 15: fast path valid
   uint16_t w1[4];    // right-tap weight per pixel (left = 2048 - w1)
-  uint16_t pad[2];
+  uint16_t nvalid;   // pixels of this dword inside the padded width (1..4); the rest store 0
+  uint16_t pad;
 };
 
 struct LevelDesc {
