@@ -149,6 +149,12 @@ int orbx_debug_sort_records(int device_id, uint64_t* records, int n);
  * of the last call per stage. */
 int orbx_set_profiling(orbx_extractor* ex, int enabled);
 int orbx_stage_times(orbx_extractor* ex, float* ms, int n);
+/* Detection-kernel launches of the last batched call in the normal
+ * (non-profiling) schedule, where a large batch runs as two parts on two
+ * streams: per launch the HIP-event duration in milliseconds, measured on the
+ * stream it ran on, and the frames it covered.  Waits for the call. */
+int orbx_detect_launch_times(orbx_extractor* ex, float* ms, int32_t* frames, int cap,
+                             int* n_launches);
 
 /* ---- Hamming matching ------------------------------------------------------ */
 /* ORBmatcher::DescriptorDistance, core/lib/ORB/matcher.cc:1961-1975 (host). */

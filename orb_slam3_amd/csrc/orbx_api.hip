@@ -158,6 +158,10 @@ struct orbx_extractor {
   int lastFrames = 0;
   bool profiling = false;
   hipEvent_t ev[ORBX_NUM_STAGES + 1] = {};
+  // normal schedule: events around the detection kernel of every part of the last call
+  hipEvent_t evDet[2][2] = {};
+  int detFrames[2] = {0, 0};
+  int lastParts = 0;
   bool evValid = false;
 
   void buildTables();
@@ -475,6 +479,7 @@ int orbx_extractor::run(const uint8_t* d_images, int istride, size_t iframe, int
                         int lap1) {
   hipStream_t s = stream;
   const bool prof = profiling;
+  lastParts = 0;
   if (prof) {
     // timing mode: one stream, stages back to back, HIP events around each stage
     HIP_TRY(hipEventRecord(ev[0], s));
@@ -501,11 +506,14 @@ int orbx_extractor::run(const uint8_t* d_images, int istride, size_t iframe, int
     // overlaps the VALU-bound detection of the part before it, and its detection overlaps
     // that part's quadtree and descriptors.
     const int nparts = std::max(1, std::min(kMaxParts, nframes / kSplitMin));
-    auto part = [&](hipStream_t m, hipStream_t side, hipEvent_t fork, hipEvent_t join, int f0, int n,
+    auto part = [&](int pk, hipStream_t m, hipStream_t side, hipEvent_t fork, hipEvent_t join, int f0, int n,
                     hipEvent_t pyrDone) -> int {
       orbx::launch_pyramid(hp, d_images, istride, iframe, d_pyr, f0, n, m);
       if (pyrDone) HIP_TRY(hipEventRecord(pyrDone, m));
+      HIP_TRY(hipEventRecord(evDet[pk][0], m));
       orbx::launch_fast(hp, dp, d_pyr, d_cand, d_cellCount, 0, hp.nlevels, f0, n, m);
+      HIP_TRY(hipEventRecord(evDet[pk][1], m));
+      detFrames[pk] = n;
       HIP_TRY(hipEventRecord(fork, m));
       HIP_TRY(hipStreamWaitEvent(side, fork, 0));
       orbx::launch_blur(hp, dp, d_pyr, d_blur, f0, n, side);
@@ -527,11 +535,12 @@ int orbx_extractor::run(const uint8_t* d_images, int istride, size_t iframe, int
       hipStream_t m = odd ? lane[1] : s;
       // a part starts its pyramid when the previous part's pyramid is done
       if (k > 0) HIP_TRY(hipStreamWaitEvent(m, evPyr[k - 1], 0));
-      const int st = part(m, odd ? lane[2] : lane[0], odd ? evForkB : evFork, odd ? evJoin[2] : evJoin[0],
+      const int st = part(k, m, odd ? lane[2] : lane[0], odd ? evForkB : evFork, odd ? evJoin[2] : evJoin[0],
                           f0, n, k + 1 < nparts ? evPyr[k] : nullptr);
       if (st != ORBX_OK) return st;
       f0 += n;
     }
+    lastParts = nparts;
     if (nparts > 1) {
       HIP_TRY(hipEventRecord(evJoin[1], lane[1]));
       HIP_TRY(hipStreamWaitEvent(s, evJoin[1], 0));
@@ -583,6 +592,8 @@ int orbx_create(const orbx_params* p, orbx_extractor** out) {
   }
   for (int i = 0; i <= ORBX_NUM_STAGES; ++i)
     if (hipEventCreate(&ex->ev[i]) != hipSuccess) { orbx_destroy(ex); return ORBX_ERR_NO_DEVICE; }
+  for (int i = 0; i < 4; ++i)
+    if (hipEventCreate(&ex->evDet[i >> 1][i & 1]) != hipSuccess) { orbx_destroy(ex); return ORBX_ERR_NO_DEVICE; }
   bool ok = hipEventCreateWithFlags(&ex->evFork, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&ex->evStart, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&ex->evForkB, hipEventDisableTiming) == hipSuccess;
@@ -601,6 +612,7 @@ void orbx_destroy(orbx_extractor* ex) {
   (void)hipSetDevice(ex->device);
   ex->freePlan();
   for (int i = 0; i <= ORBX_NUM_STAGES; ++i) if (ex->ev[i]) (void)hipEventDestroy(ex->ev[i]);
+  for (int i = 0; i < 4; ++i) if (ex->evDet[i >> 1][i & 1]) (void)hipEventDestroy(ex->evDet[i >> 1][i & 1]);
   for (int k = 0; k < orbx_extractor::kLanes; ++k) {
     if (ex->lane[k]) { (void)hipStreamSynchronize(ex->lane[k]); (void)hipStreamDestroy(ex->lane[k]); }
     if (ex->evJoin[k]) (void)hipEventDestroy(ex->evJoin[k]);
@@ -1091,6 +1103,19 @@ int orbx_stage_times(orbx_extractor* ex, float* ms, int n) {
   for (int i = 0; i < ORBX_NUM_STAGES && e == hipSuccess; ++i)
     e = hipEventElapsedTime(&ms[i], ex->ev[i], ex->ev[i + 1]);
   if (e != hipSuccess) { ex->last_hip_error = e; return ORBX_ERR_HIP; }
+  return ORBX_OK;
+}
+
+int orbx_detect_launch_times(orbx_extractor* ex, float* ms, int32_t* frames, int cap, int* n_launches) {
+  if (!ex || !ms || !frames || !n_launches || ex->lastParts <= 0 || cap < ex->lastParts) return ORBX_ERR_BAD_ARG;
+  if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  hipError_t e = hipStreamSynchronize(ex->stream);
+  for (int k = 0; k < ex->lastParts && e == hipSuccess; ++k) {
+    e = hipEventElapsedTime(&ms[k], ex->evDet[k][0], ex->evDet[k][1]);
+    frames[k] = ex->detFrames[k];
+  }
+  if (e != hipSuccess) { ex->last_hip_error = e; return ORBX_ERR_HIP; }
+  *n_launches = ex->lastParts;
   return ORBX_OK;
 }
 

@@ -162,6 +162,15 @@ class ORBextractor:
         return dict(zip(_lib.STAGE_NAMES, ms.tolist()))
 
     # --- stage dumps ------------------------------------------------------------------
+    def detect_launch_times(self):
+        """[(milliseconds, frames)] of the detection-kernel launches of the last batched call in the
+        normal schedule."""
+        ms = (C.c_float * 4)()
+        fr = (C.c_int32 * 4)()
+        n = C.c_int32()
+        check(lib().orbx_detect_launch_times(self._h, ms, fr, 4, C.byref(n)), "orbx_detect_launch_times")
+        return [(float(ms[i]), int(fr[i])) for i in range(n.value)]
+
     def level_dims(self, level):
         w, h, s = C.c_int32(), C.c_int32(), C.c_int32()
         check(lib().orbx_level_dims(self._h, level, C.byref(w), C.byref(h), C.byref(s)))

@@ -24,21 +24,32 @@ def main():
     out, tag = sys.argv[1], sys.argv[2]
     for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
         shutil.copy(f, os.path.join(out, "%s_kernel_stats.csv" % tag))
-    summ = {}
+    # A kernel may run at several grid sizes in one bench run (half batches on two streams in
+    # the timed loop, whole batches in the per-stage timing pass): only the largest grid of each
+    # kernel, i.e. the whole-batch launch the bench's per-stage times refer to, is summarised.
+    rows = []
     for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
         for f in glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True):
             with open(f, newline="") as fh:
                 for row in csv.DictReader(fh):
                     k = short(row["Kernel_Name"])
-                    if not k.startswith("k_"):
-                        continue
-                    e = summ.setdefault(k, {}).setdefault(row["Counter_Name"], [0.0, 0])
-                    e[0] += float(row["Counter_Value"])
-                    e[1] += 1
+                    if k.startswith("k_"):
+                        rows.append((k, int(row["Grid_Size"]), row["Counter_Name"], float(row["Counter_Value"])))
+    biggest = {}
+    for k, g, _, _ in rows:
+        biggest[k] = max(biggest.get(k, 0), g)
+    summ = {}
+    for k, g, c, v in rows:
+        if g != biggest[k]:
+            continue
+        e = summ.setdefault(k, {}).setdefault(c, [0.0, 0])
+        e[0] += v
+        e[1] += 1
     res = {}
     for k, cs in sorted(summ.items()):
         r = {c: v[0] / v[1] for c, v in cs.items()}
         r["launches_sampled"] = max(v[1] for v in cs.values())
+        r["grid_size"] = biggest[k]
         if "FETCH_SIZE" in r:
             r["hbm_read_bytes_raw"] = r["FETCH_SIZE"] * 1024
             r["hbm_read_bytes_x2"] = r["FETCH_SIZE"] * 2048
