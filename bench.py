@@ -188,7 +188,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024, help="frames per step per GPU")
-    ap.add_argument("--no-match", action="store_true", help="skip the Hamming 2-NN and stereo legs")
+    ap.add_argument("--no-match", action="store_true", help="skip the Hamming 2-NN leg")
+    ap.add_argument("--stereo", action="store_true",
+                    help="add the stereo leg (752x480 pairs, 2x1200 kp: both extractions + ComputeStereoMatches)")
     ap.add_argument("--distinct", type=int, default=32, help="distinct synthetic frames (tiled to the batch)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--stage-times", action="store_true",
@@ -297,6 +299,7 @@ def main():
         }
         if not args.no_match:
             out["hamming"] = hamming_bench(torch, orbx, dev)
+        if args.stereo:
             out["stereo"] = stereo_bench(torch, orbx, dev, local_rank)
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames)
