@@ -1183,6 +1183,7 @@ __global__ __launch_bounds__(256) void k_assemble(const Plan* __restrict__ plan,
                                                   int f0) {
   __shared__ int lvOff[ORBX_MAX_LEVELS + 1];
   __shared__ int waveCnt[4];
+  __shared__ int binCur[ORBX_MAX_LEVELS * 32];
   const int f = blockIdx.x + f0, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nl = plan->nlevels;
   if (tid == 0) {
@@ -1195,6 +1196,35 @@ __global__ __launch_bounds__(256) void k_assemble(const Plan* __restrict__ plan,
   }
   __syncthreads();
   const int n = lvOff[nl];
+  // The work list of the orientation/descriptor kernel is ordered by (level, band of rows), not
+  // by output slot: keypoints that follow each other there then read overlapping image rows, and
+  // most of their window lines are still in the vector cache.  Counting sort over 32 bands per
+  // level; the order inside a band is whatever the atomics give (every item carries its slot).
+  for (int b = tid; b < ORBX_MAX_LEVELS * 32; b += 256) binCur[b] = 0;
+  __syncthreads();
+  for (int k = tid; k < n; k += 256) {
+    int l = 0;
+    while (k >= lvOff[l + 1]) ++l;
+    const uint32_t key = sel[(size_t)f * plan->sel_frame + plan->lv[l].sel_off + (k - lvOff[l])];
+    const int y = (int)((key >> 12) & 0xFFF) + ORBX_DET_ORG;
+    atomicAdd(&binCur[l * 32 + min(31, (y * 32) / plan->lv[l].h)], 1);
+  }
+  __syncthreads();
+  if (tid < 64) {   // exclusive scan of the 512 bins by one wave, 8 per lane
+    int v[8], t = 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { v[u] = binCur[tid * 8 + u]; t += v[u]; }
+    int inc = t;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(inc, d);
+      if (tid >= d) inc += o;
+    }
+    int run = inc - t;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { binCur[tid * 8 + u] = run; run += v[u]; }
+  }
+  __syncthreads();
   const float flap0 = (float)lap0, flap1 = (float)lap1;
   int stereoBefore = 0;  // stereo keys in earlier chunks
   float* kout = kps + (size_t)f * plan->kp_cap * 7;
@@ -1240,7 +1270,8 @@ __global__ __launch_bounds__(256) void k_assemble(const Plan* __restrict__ plan,
       wi.xy = ((key & 0xFFF) + ORBX_DET_ORG) | ((((key >> 12) & 0xFFF) + ORBX_DET_ORG) << 16);
       wi.dst = dst;
       wi.pad = 0;
-      wout[k] = wi;
+      const int yl = (int)((key >> 12) & 0xFFF) + ORBX_DET_ORG;
+      wout[atomicAdd(&binCur[l * 32 + min(31, (yl * 32) / plan->lv[l].h)], 1)] = wi;
     }
     stereoBefore += chunkTotal;
     __syncthreads();
@@ -1383,12 +1414,16 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 
 // 16 lanes per keypoint, 4 keypoints per wave, 16 per block.
 //  * moments: lane j of a group owns patch columns u = 2j-15 and 2j-14 and walks the
-//    31 rows of the patch, which is staged in LDS by row-wise dword loads;
+//    31 rows of the patch, which is staged in LDS by row-wise 16-byte loads;
 //  * descriptor: lane j evaluates tests 16j .. 16j+15 = descriptor bytes 2j, 2j+1.
-#define DESC_WIN_DW 370   // 37 rows x 10 dwords
-#define DESC_STAGE 24     // dwords per lane (16 lanes per keypoint)
-#define IC_WIN_DW 279     // 31 rows x 9 dwords
-#define IC_STAGE 18
+// Both windows are staged with 16-byte loads, three per row (48 bytes cover the 36 / 40 bytes
+// a row needs from its dword-aligned start), so a window row is 12 dwords in LDS.
+#define WIN_ROW_DW 12
+#define DESC_WIN_DW (37 * WIN_ROW_DW)   // 37 rows
+#define DESC_CHUNKS (37 * 3)
+#define DESC_STAGE 7                    // 16-byte chunks per lane (16 lanes per keypoint)
+#define IC_CHUNKS (31 * 3)
+#define IC_STAGE 6
 __global__ __launch_bounds__(256) void k_orient_describe(const Plan* __restrict__ plan,
                                                          const uint8_t* __restrict__ pyr,
                                                          const uint8_t* __restrict__ blur,
@@ -1415,7 +1450,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Plan* __restrict_
 
   // ---- IC_Angle on the un-blurred level (extractor.cc:75-99) ----------------
   // the 31 x 31 patch goes through the same LDS window as the blurred one below
-  __shared__ uint32_t sWin[16][DESC_WIN_DW];
+  __shared__ __align__(16) uint32_t sWin[16][DESC_WIN_DW];
   const int slotInBlock = (int)(threadIdx.x >> 6) * 4 + g;
   const int u0 = 2 * j16 - 15, u1 = u0 + 1;
   const int au0 = u0 < 0 ? -u0 : u0, au1 = u1 < 0 ? -u1 : u1;
@@ -1423,12 +1458,13 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Plan* __restrict_
   {
     const int px0 = (cx + ORBX_EDGE - 15) & ~3;   // padded column of the window's first dword
     const uint8_t* pbase = pyr + L.pyr_off + (size_t)f * L.pyr_plane + (size_t)(cy + ORBX_EDGE - 15) * ps + px0;
-    uint32_t st2[IC_STAGE];
+    uint4 st2[IC_STAGE];
 #pragma unroll
     for (int u = 0; u < IC_STAGE; ++u) {
-      const int idx = min(j16 + 16 * u, IC_WIN_DW - 1);
-      const int r = idx / 9, c9 = idx - r * 9;
-      st2[u] = *(const uint32_t*)(pbase + (size_t)r * ps + 4 * c9);
+      const int idx = min(j16 + 16 * u, IC_CHUNKS - 1);
+      const int r = idx / 3, c3 = idx - r * 3;
+      const U4A4 t = *(const U4A4*)(pbase + (size_t)r * ps + 16 * c3);
+      st2[u] = make_uint4(t.x, t.y, t.z, t.w);
     }
     int um[16];
 #pragma unroll
@@ -1436,15 +1472,15 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Plan* __restrict_
 #pragma unroll
     for (int u = 0; u < IC_STAGE; ++u) {
       const int idx = j16 + 16 * u;
-      if (idx < IC_WIN_DW) sWin[slotInBlock][idx] = st2[u];
+      if (idx < IC_CHUNKS) *(uint4*)&sWin[slotInBlock][4 * idx] = st2[u];
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    const uint8_t* center = (const uint8_t*)sWin[slotInBlock] + 15 * 36 + (cx + ORBX_EDGE - px0);
+    const uint8_t* center = (const uint8_t*)sWin[slotInBlock] + 15 * (4 * WIN_ROW_DW) + (cx + ORBX_EDGE - px0);
 #pragma unroll
     for (int v = -15; v <= 15; ++v) {
       const int lim = um[v < 0 ? -v : v];
-      const uint8_t* rp = center + v * 36;
+      const uint8_t* rp = center + v * (4 * WIN_ROW_DW);
       const int a = au0 <= lim ? (int)rp[u0] : 0;
       const int b = au1 <= lim ? (int)rp[u1] : 0;   // u1 = 16 never passes (lim <= 15)
       m10 += __mul24(u0, a) + __mul24(u1, b);
@@ -1462,16 +1498,17 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Plan* __restrict_
 
   // ---- steered BRIEF on the blurred level (extractor.cc:102-145) ------------
   // The 37 x 37 window the 512 sample points can fall into (reach 18) is staged in LDS
-  // with row-wise dword loads (issued before the trigonometry so they overlap it); the
+  // with row-wise 16-byte loads (issued before the trigonometry so they overlap it); the
   // rotated samples are then LDS byte reads instead of scattered global gathers.
   const int bx0 = (cx - 18) & ~3;
   const uint8_t* wbase = blur + L.blur_off + (size_t)f * L.blur_plane + (size_t)(cy - 18) * bs + bx0;
-  uint32_t stage[DESC_STAGE];
+  uint4 stage[DESC_STAGE];
 #pragma unroll
   for (int u = 0; u < DESC_STAGE; ++u) {
-    const int idx = min(j16 + 16 * u, DESC_WIN_DW - 1);
-    const int r = idx / 10, c10 = idx - r * 10;
-    stage[u] = *(const uint32_t*)(wbase + (size_t)r * bs + 4 * c10);
+    const int idx = min(j16 + 16 * u, DESC_CHUNKS - 1);
+    const int r = idx / 3, c3 = idx - r * 3;
+    const U4A4 t = *(const U4A4*)(wbase + (size_t)r * bs + 16 * c3);
+    stage[u] = make_uint4(t.x, t.y, t.z, t.w);
   }
   const float factorPI = (float)(3.1415926535897932384626433832795 / 180.0);
   const float rad = __fmul_rn(angle, factorPI);
@@ -1479,11 +1516,11 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Plan* __restrict_
 #pragma unroll
   for (int u = 0; u < DESC_STAGE; ++u) {
     const int idx = j16 + 16 * u;
-    if (idx < DESC_WIN_DW) sWin[slotInBlock][idx] = stage[u];
+    if (idx < DESC_CHUNKS) *(uint4*)&sWin[slotInBlock][4 * idx] = stage[u];
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
-  const uint8_t* bc = (const uint8_t*)sWin[slotInBlock] + 18 * 40 + (cx - bx0);
+  const uint8_t* bc = (const uint8_t*)sWin[slotInBlock] + 18 * (4 * WIN_ROW_DW) + (cx - bx0);
   const uint4* pp = (const uint4*)(c_pattern + 64 * j16);
   uint32_t bits = 0;
 #pragma unroll
@@ -1499,8 +1536,8 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Plan* __restrict_
       const int q0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
       const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
       const int q1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-      const int t0 = bc[r0 * 40 + q0];
-      const int t1 = bc[r1 * 40 + q1];
+      const int t0 = bc[r0 * (4 * WIN_ROW_DW) + q0];
+      const int t1 = bc[r1 * (4 * WIN_ROW_DW) + q1];
       bits |= (t0 < t1 ? 1u : 0u) << (q * 4 + e);
     }
   }
