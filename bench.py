@@ -306,8 +306,9 @@ def main():
             out["gpu_over_cpu"] = fps / out["cpu_baseline"]["value"]
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()   # the other ranks wait here while rank 0 finishes its single-rank legs
         dist.destroy_process_group()
 
 
