@@ -1,0 +1,268 @@
+"""A second, independent restatement (numpy, written from the published algorithms, not from
+oracle/orb_oracle.cpp) of the pixel-level stages of the ORB front-end.  Test infrastructure
+only: tests/test_spec_crosscheck.py runs it beside the C++ oracle on small images so that a
+slip in either restatement shows up as a difference.  Slow on purpose (clarity first).
+
+Stage -> reference call site (paths relative to the ORB-SLAM3 tree):
+  resize_linear_u8    cv::resize(INTER_LINEAR), core/lib/ORB/extractor.cc:1116
+  reflect101_pad      cv::copyMakeBorder(BORDER_REFLECT_101), :1119-1124
+  gaussian7           cv::GaussianBlur(7x7, sigma 2), :1064
+  fast_cell           cv::FAST(roi, kps, threshold, true), :789, :806
+  level_candidates    the cell loop of ComputeKeyPointsOctTree, :747-831
+  ic_angle            IC_Angle + cv::fastAtan2, :75-99
+  brief_descriptor    computeOrbDescriptor, :102-145
+"""
+import os
+
+import numpy as np
+
+EDGE = 19
+F32 = np.float32
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def cv_round(v):
+    """OpenCV's cvRound: round half to even."""
+    return int(np.rint(v))
+
+
+def level_tables(nlevels, scale_factor):
+    scale = [F32(1.0)]
+    sf = float(F32(scale_factor))          # the reference keeps the float argument in a double
+    for _ in range(1, nlevels):
+        scale.append(F32(float(scale[-1]) * sf))
+    inv = [F32(1.0) / s for s in scale]
+    return scale, inv
+
+
+def level_size(W, H, inv_scale):
+    return cv_round(F32(W) * inv_scale), cv_round(F32(H) * inv_scale)
+
+
+# ---- cv::resize, INTER_LINEAR, 8-bit single channel ---------------------------------------------
+def _axis_taps(sn, dn, horizontal):
+    scale = 1.0 / (float(dn) / sn)
+    out = []
+    for d in range(dn):
+        fx = F32((d + 0.5) * scale - 0.5)
+        s = int(np.floor(fx))
+        fx = F32(fx - F32(s))
+        if horizontal:
+            if s < 0:
+                s, fx = 0, F32(0)
+            if s >= sn - 1:
+                s, fx = sn - 1, F32(0)
+            s0, s1 = s, min(s + 1, sn - 1)
+        else:
+            s0, s1 = min(max(s, 0), sn - 1), min(max(s + 1, 0), sn - 1)
+        w0 = int(np.clip(cv_round(F32(F32(1.0) - fx) * F32(2048)), -32768, 32767))
+        w1 = int(np.clip(cv_round(fx * F32(2048)), -32768, 32767))
+        out.append((s0, s1, w0, w1))
+    return out
+
+
+def resize_linear_u8(src, dw, dh):
+    sh, sw = src.shape
+    xt = _axis_taps(sw, dw, True)
+    yt = _axis_taps(sh, dh, False)
+    s = src.astype(np.int64)
+    hrows = np.empty((sh, dw), np.int64)
+    for dx, (s0, s1, a0, a1) in enumerate(xt):
+        hrows[:, dx] = s[:, s0] * a0 + s[:, s1] * a1
+    dst = np.empty((dh, dw), np.uint8)
+    for dy, (r0, r1, b0, b1) in enumerate(yt):
+        v = (((b0 * (hrows[r0] >> 4)) >> 16) + ((b1 * (hrows[r1] >> 4)) >> 16) + 2) >> 2
+        dst[dy] = np.clip(v, 0, 255).astype(np.uint8)
+    return dst
+
+
+def reflect101_pad(img, border=EDGE):
+    return np.pad(img, border, mode="reflect")      # numpy's "reflect" is gfedcb|abcdefgh|gfedcba
+
+
+def build_pyramid(image, nlevels, scale_factor):
+    """List of padded levels (19-pixel border), as ComputePyramid leaves them."""
+    H, W = image.shape
+    _, inv = level_tables(nlevels, scale_factor)
+    levels, padded = [], []
+    for l in range(nlevels):
+        w, h = level_size(W, H, inv[l])
+        lv = image.copy() if l == 0 else resize_linear_u8(levels[l - 1], w, h)
+        levels.append(lv)
+        padded.append(reflect101_pad(lv))
+    return levels, padded
+
+
+# ---- cv::GaussianBlur 7x7, sigma 2: OpenCV's fixed-point path -------------------------------------
+GAUSS7 = np.array([18, 34, 48, 56, 48, 34, 18], np.int64)   # 8.8 fixed point, sum 256
+
+
+def gaussian7(img):
+    p = np.pad(img, 3, mode="reflect").astype(np.int64)
+    h, w = img.shape
+    rows = sum(GAUSS7[i] * p[:, i:i + w] for i in range(7))            # (h+6, w), < 2^16
+    cols = sum(GAUSS7[j] * rows[j:j + h, :] for j in range(7))
+    return ((cols + 32768) >> 16).astype(np.uint8)
+
+
+# ---- cv::FAST, TYPE_9_16, with non-max suppression -----------------------------------------------
+RING = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2),
+        (-3, -1), (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+
+
+def fast_strength(img):
+    """m(x, y) = max over the 16 arcs of 9 contiguous ring pixels, and both signs, of the
+    smallest |I_k - v| with all nine differences of that sign; 0 where no such arc exists.
+    A pixel is a corner at threshold t iff m > t and its OpenCV score is m - 1.
+    Defined for 3 <= x < cols-3, 3 <= y < rows-3; 0 elsewhere."""
+    h, w = img.shape
+    m = np.zeros((h, w), np.int32)
+    v = img[3:h - 3, 3:w - 3].astype(np.int32)
+    d = np.stack([v - img[3 + dy:h - 3 + dy, 3 + dx:w - 3 + dx].astype(np.int32) for dx, dy in RING])
+    best = np.zeros_like(v)
+    for k in range(16):
+        idx = [(k + i) % 16 for i in range(9)]
+        arc = d[idx]
+        best = np.maximum(best, arc.min(axis=0))        # darker ring: all v - I_k > 0
+        best = np.maximum(best, (-arc).min(axis=0))     # brighter ring
+    m[3:h - 3, 3:w - 3] = np.maximum(best, 0)
+    return m
+
+
+def fast_cell(roi, threshold):
+    """cv::FAST(roi, keypoints, threshold, nonmaxSuppression=true): [(x, y, score)], rows then x."""
+    m = fast_strength(roi)
+    score = np.where(m > threshold, m - 1, 0)            # non-corners count as 0 in the suppression
+    out = []
+    h, w = roi.shape
+    for y in range(3, h - 3):
+        for x in range(3, w - 3):
+            if m[y, x] <= threshold:
+                continue
+            s = score[y, x]
+            nb = score[y - 1:y + 2, x - 1:x + 2].copy()
+            nb[1, 1] = -1
+            if (s > nb).all():
+                out.append((x, y, int(s)))
+    return out
+
+
+def level_candidates(padded_level, w, h, ini_th, min_th):
+    """The 35-pixel cell loop: candidates (x, y, score) relative to (16, 16), in emission order."""
+    # minBorder = EDGE_THRESHOLD - 3, maxBorder = cols/rows - EDGE_THRESHOLD + 3, level coordinates
+    min_bx, min_by = EDGE - 3, EDGE - 3
+    max_bx, max_by = w - EDGE + 3, h - EDGE + 3
+    width, height = F32(max_bx - min_bx), F32(max_by - min_by)
+    n_cols, n_rows = int(width / F32(35)), int(height / F32(35))
+    w_cell = int(np.ceil(width / F32(n_cols)))
+    h_cell = int(np.ceil(height / F32(n_rows)))
+
+    def region(x0, x1, y0, y1):
+        return padded_level[EDGE + y0:EDGE + y1, EDGE + x0:EDGE + x1]
+
+    out = []
+    for i in range(n_rows):
+        ini_y = min_by + i * h_cell
+        max_y = ini_y + h_cell + 6
+        if ini_y >= max_by - 3:
+            continue
+        max_y = min(max_y, max_by)
+        for j in range(n_cols):
+            ini_x = min_bx + j * w_cell
+            max_x = ini_x + w_cell + 6
+            if ini_x >= max_bx - 6:
+                continue
+            max_x = min(max_x, max_bx)
+            roi = region(ini_x, max_x, ini_y, max_y)
+            keys = fast_cell(roi, ini_th)
+            if not keys:
+                keys = fast_cell(roi, min_th)
+            for x, y, s in keys:
+                out.append((x + j * w_cell, y + i * h_cell, s))
+    return out
+
+
+# ---- IC_Angle + fastAtan2 ----------------------------------------------------------------------------
+def umax_table():
+    half = 15
+    vmax = int(np.floor(half * np.sqrt(F32(2.0)) / 2 + 1))
+    vmin = int(np.ceil(half * np.sqrt(F32(2.0)) / 2))
+    um = [0] * (half + 1)
+    for v in range(vmax + 1):
+        um[v] = cv_round(np.sqrt(float(half * half - v * v)))
+    v0 = 0
+    for v in range(half, vmin - 1, -1):
+        while um[v0] == um[v0 + 1]:
+            v0 += 1
+        um[v] = v0
+        v0 += 1
+    return um
+
+
+def fast_atan2(y, x):
+    """cv::fastAtan2 (degrees, [0, 360)), float arithmetic without fused multiply-add."""
+    y, x = F32(y), F32(x)
+    scale = F32(180.0 / np.pi)
+    p1 = F32(0.9997878412794807) * scale
+    p3 = F32(-0.3258083974640975) * scale
+    p5 = F32(0.1555786518463281) * scale
+    p7 = F32(-0.04432655554792128) * scale
+    ax, ay = np.abs(x), np.abs(y)
+    eps = F32(2.220446049250313e-16)
+    if ax >= ay:
+        c = ay / (ax + eps)
+        c2 = c * c
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c
+    else:
+        c = ax / (ay + eps)
+        c2 = c * c
+        a = F32(90.0) - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c
+    if x < 0:
+        a = F32(180.0) - a
+    if y < 0:
+        a = F32(360.0) - a
+    return F32(a)
+
+
+def ic_moments(padded_level, x, y):
+    um = umax_table()
+    cx, cy = EDGE + int(x), EDGE + int(y)
+    m10 = m01 = 0
+    for v in range(-15, 16):
+        for u in range(-um[abs(v)], um[abs(v)] + 1):
+            val = int(padded_level[cy + v, cx + u])
+            m10 += u * val
+            m01 += v * val
+    return m10, m01
+
+
+# ---- rotated BRIEF ---------------------------------------------------------------------------------------
+def load_pattern():
+    txt = open(os.path.join(ROOT, "oracle", "orb_pattern_31.inc")).read()
+    txt = txt[txt.index("*/") + 2:]
+    vals = [int(t) for t in txt.replace("\n", " ").split(",") if t.strip()]
+    assert len(vals) == 1024
+    return np.array(vals, np.int32).reshape(256, 4)
+
+
+def brief_descriptor(blurred_level, x, y, angle_deg, pattern):
+    """256 tests on the blurred level image around (x, y); sample offsets are rotated by the
+    keypoint angle and rounded half-to-even; bit j of byte i is test 8i + j."""
+    factor_pi = F32(np.pi / 180.0)
+    rad = F32(angle_deg) * factor_pi
+    a = F32(np.cos(float(rad)))
+    b = F32(np.sin(float(rad)))
+    cx, cy = int(x), int(y)
+    desc = np.zeros(32, np.uint8)
+
+    def sample(px, py):
+        px, py = F32(px), F32(py)
+        row = cv_round(px * b + py * a)
+        col = cv_round(px * a - py * b)
+        return int(blurred_level[cy + row, cx + col])
+
+    for t in range(256):
+        x0, y0, x1, y1 = pattern[t]
+        if sample(x0, y0) < sample(x1, y1):
+            desc[t >> 3] |= 1 << (t & 7)
+    return desc

@@ -1,0 +1,103 @@
+"""The C++ oracle against an independent numpy restatement of the same published algorithms
+(tests/numpy_spec.py) on small images, stage by stage: pyramid, blur, per-cell FAST candidates,
+moments and angles, descriptors.  Two restatements written separately agreeing bit for bit is
+what stands in for the missing reference fixtures on the CPU side."""
+import numpy as np
+import pytest
+
+from tests import numpy_spec as S
+
+PARAMS = (300, 1.2, 4, 20, 7)
+
+
+@pytest.fixture(scope="module")
+def case(oracle):
+    import orb_slam3_amd as orbx
+    img = orbx.textured_frame(17, 214, 160)
+    e = oracle.Extractor(*PARAMS)
+    st, mono, k, d = e.extract(img, (0, 0))
+    assert st == 0 and len(k) > 100
+    levels, padded = S.build_pyramid(img, PARAMS[2], PARAMS[1])
+    return dict(img=img, e=e, k=k, d=d, levels=levels, padded=padded)
+
+
+def test_tables_and_level_sizes(oracle, case):
+    scale, inv = S.level_tables(PARAMS[2], PARAMS[1])
+    t = case["e"].tables()
+    assert np.array_equal(np.array(scale, np.float32), t["scale"])
+    assert np.array_equal(np.array(inv, np.float32), t["inv"])
+    assert S.umax_table() == t["umax"].tolist()
+    for l in range(PARAMS[2]):
+        w, h, _ = case["e"].level_dims(l)
+        assert (w, h) == S.level_size(214, 160, inv[l])
+
+
+def test_pyramid_bytes(case):
+    for l in range(PARAMS[2]):
+        w, h, _ = case["e"].level_dims(l)
+        assert np.array_equal(case["e"].padded(l)[:, :w + 38], case["padded"][l]), l
+
+
+def test_blur_bytes(case):
+    for l in range(PARAMS[2]):
+        b = case["e"].blurred(l)
+        if b is not None:
+            assert np.array_equal(b, S.gaussian7(case["levels"][l])), l
+
+
+def test_resize_and_blur_on_odd_sizes(oracle):
+    rng = np.random.default_rng(2)
+    for sw, sh, dw, dh in [(67, 50, 56, 42), (101, 77, 84, 64), (40, 33, 20, 17), (35, 35, 34, 34)]:
+        src = rng.integers(0, 256, (sh, sw), dtype=np.uint8)
+        assert np.array_equal(oracle.resize(src, dw, dh), S.resize_linear_u8(src, dw, dh))
+        assert np.array_equal(oracle.gauss7(src), S.gaussian7(src))
+
+
+def test_fast_on_random_cells(oracle):
+    rng = np.random.default_rng(3)
+    import orb_slam3_amd as orbx
+    img = orbx.textured_frame(5, 300, 200)
+    for i in range(25):
+        cw, ch = rng.integers(20, 60, 2)
+        x0, y0 = rng.integers(0, 300 - cw), rng.integers(0, 200 - ch)
+        roi = np.ascontiguousarray(img[y0:y0 + ch, x0:x0 + cw])
+        for th in (7, 20):
+            got = [tuple(r) for r in oracle.fast(roi, th).tolist()]
+            assert got == S.fast_cell(roi, th), (i, th)
+    noise = rng.integers(0, 256, (40, 45), dtype=np.uint8)     # dense corners, many score ties
+    assert [tuple(r) for r in oracle.fast(noise, 7).tolist()] == S.fast_cell(noise, 7)
+
+
+def test_cell_candidates(case):
+    for l in range(PARAMS[2]):
+        w, h, _ = case["e"].level_dims(l)
+        want = S.level_candidates(case["padded"][l], w, h, PARAMS[3], PARAMS[4])
+        got = [tuple(r) for r in case["e"].candidates(l).tolist()]
+        assert got == want, l
+        assert len(got) > 20
+
+
+def test_moments_angles_and_descriptors(case):
+    pattern = S.load_pattern()
+    scale, _ = S.level_tables(PARAMS[2], PARAMS[1])
+    out = 0
+    for l in range(PARAMS[2]):
+        kl, mom = case["e"].keys(l)
+        blurred = case["e"].blurred(l)
+        # the reflected border is part of what the descriptor may sample near the image edge
+        bl_pad = np.pad(S.gaussian7(case["levels"][l]), 19, mode="reflect") if blurred is not None else None
+        for i in range(len(kl)):
+            x, y = int(kl["x"][i]), int(kl["y"][i])
+            m10, m01 = S.ic_moments(case["padded"][l], x, y)
+            assert (m10, m01) == tuple(mom[i]), (l, i)
+            ang = S.fast_atan2(m01, m10)
+            assert ang == kl["angle"][i], (l, i)
+            # final keypoint and descriptor (vLappingArea (0,0): output order = level order)
+            k = case["k"][out]
+            assert k["octave"] == l and k["angle"] == ang
+            sx = np.float32(x) * scale[l] if l else np.float32(x)
+            assert k["x"] == sx
+            want = S.brief_descriptor(bl_pad[19:, 19:], x, y, ang, pattern)
+            assert np.array_equal(case["d"][out], want), (l, i)
+            out += 1
+    assert out == len(case["k"])
