@@ -266,3 +266,153 @@ def brief_descriptor(blurred_level, x, y, angle_deg, pattern):
         if sample(x0, y0) < sample(x1, y1):
             desc[t >> 3] |= 1 << (t & 7)
     return desc
+
+
+# ---- Frame::ComputeStereoMatches, core/src/Frame.cc:831-996 -----------------------------------------
+def hamming(a, b):
+    return int(np.unpackbits(np.bitwise_xor(a, b)).sum())
+
+
+def c_round(v):
+    """C round(): half away from zero, on a float."""
+    v = float(v)
+    return np.floor(v + 0.5) if v >= 0 else np.ceil(v - 0.5)
+
+
+def stereo_matches(levels_l, levels_r, scale, inv_scale, kl, dl, kr, dr, mbf, mb):
+    """levels_*: un-padded level images of the two cameras; kl/kr: keypoint records with fields
+    x, y, octave; returns (uRight, depth) float32 arrays."""
+    mbf, mb = F32(mbf), F32(mb)
+    n = len(kl)
+    u_right = np.full(n, -1, np.float32)
+    depth = np.full(n, -1, np.float32)
+    n_rows = levels_l[0].shape[0]
+    rows = [[] for _ in range(n_rows)]
+    for ir in range(len(kr)):
+        r = F32(2.0) * scale[kr["octave"][ir]]
+        hi = int(np.ceil(kr["y"][ir] + r))
+        lo = int(np.floor(kr["y"][ir] - r))
+        for yi in range(lo, hi + 1):
+            if 0 <= yi < n_rows:
+                rows[yi].append(ir)
+    min_d, max_d = F32(0), mbf / mb
+    dist_idx = []
+    for il in range(n):
+        lvl = int(kl["octave"][il])
+        ul, vl = kl["x"][il], kl["y"][il]
+        cand = rows[int(vl)] if 0 <= int(vl) < n_rows else []
+        if not cand:
+            continue
+        min_u, max_u = ul - max_d, ul - min_d
+        if max_u < 0:
+            continue
+        best, best_r = 100, 0
+        for ir in cand:
+            if kr["octave"][ir] < lvl - 1 or kr["octave"][ir] > lvl + 1:
+                continue
+            if min_u <= kr["x"][ir] <= max_u:
+                d = hamming(dl[il], dr[ir])
+                if d < best:
+                    best, best_r = d, ir
+        if best >= (100 + 50) // 2:
+            continue
+        sf = inv_scale[lvl]
+        su = int(c_round(ul * sf))
+        sv = int(c_round(vl * sf))
+        sr = int(c_round(kr["x"][best_r] * sf))
+        il_img, ir_img = levels_l[lvl], levels_r[lvl]
+        h, w = il_img.shape
+        if sv - 5 < 0 or sv + 6 > h or su - 5 < 0 or su + 6 > w:
+            continue                     # cv::Mat::rowRange / colRange would throw
+        if sr < 0 or sr + 11 >= w or sr - 10 < 0:
+            continue
+        win_l = il_img[sv - 5:sv + 6, su - 5:su + 6].astype(np.int32)
+        dists = []
+        for inc in range(-5, 6):
+            win_r = ir_img[sv - 5:sv + 6, sr + inc - 5:sr + inc + 6].astype(np.int32)
+            dists.append(F32(np.abs(win_l - win_r).sum()))
+        best_inc = int(np.argmin(dists)) - 5          # first minimum
+        best_sad = int(min(dists))
+        if best_inc in (-5, 5):
+            continue
+        d1, d2, d3 = dists[5 + best_inc - 1], dists[5 + best_inc], dists[5 + best_inc + 1]
+        delta = (d1 - d3) / (F32(2.0) * (d1 + d3 - F32(2.0) * d2))
+        if delta < -1 or delta > 1:
+            continue
+        best_ur = scale[lvl] * (F32(sr) + F32(best_inc) + delta)
+        disparity = ul - best_ur
+        if min_d <= disparity < max_d:
+            if disparity <= 0:
+                disparity = F32(0.01)
+                best_ur = F32(float(ul) - 0.01)
+            depth[il] = mbf / disparity
+            u_right[il] = best_ur
+            dist_idx.append((best_sad, il))
+    if dist_idx:
+        dist_idx.sort()
+        median = F32(dist_idx[len(dist_idx) // 2][0])
+        th = F32(1.5) * F32(1.4) * median
+        for sad, il in reversed(dist_idx):
+            if F32(sad) < th:
+                break
+            u_right[il] = -1
+            depth[il] = -1
+    return u_right, depth
+
+
+# ---- Frame::UndistortKeyPoints / AssignFeaturesToGrid / GetFeaturesInArea ---------------------------
+def undistort_points(cam, xy):
+    """cv::undistortPoints(src, dst, K, D, noArray(), K): five fixed-point iterations, double."""
+    fx, fy, cx, cy, k1, k2, p1, p2, k3 = [float(F32(c)) for c in cam]
+    out = np.empty((len(xy), 2), np.float32)
+    for i, (u, v) in enumerate(np.asarray(xy, np.float32)):
+        u, v = float(u), float(v)
+        x = x0 = (u - cx) * (1.0 / fx)
+        y = y0 = (v - cy) * (1.0 / fy)
+        for _ in range(5):
+            r2 = x * x + y * y
+            icdist = 1.0 / (1 + ((k3 * r2 + k2) * r2 + k1) * r2)
+            if icdist < 0:
+                x, y = x0, y0
+                break
+            dx = 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+            dy = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+            x, y = (x0 - dx) * icdist, (y0 - dy) * icdist
+        out[i] = (F32(fx * x + cx), F32(fy * y + cy))
+    return out
+
+
+def frame_grid(kps_un, bounds):
+    """64 x 48 grid as a dict cell -> ascending keypoint indices, cell = posX * 48 + posY."""
+    min_x, max_x, min_y, max_y = [F32(b) for b in bounds]
+    inv_w, inv_h = F32(64) / (max_x - min_x), F32(48) / (max_y - min_y)
+    grid = {}
+    for i in range(len(kps_un)):
+        px = int(c_round((kps_un["x"][i] - min_x) * inv_w))
+        py = int(c_round((kps_un["y"][i] - min_y) * inv_h))
+        if 0 <= px < 64 and 0 <= py < 48:
+            grid.setdefault(px * 48 + py, []).append(i)
+    return grid
+
+
+def features_in_area(kps_un, grid, bounds, x, y, r, min_level, max_level):
+    min_x, max_x, min_y, max_y = [F32(b) for b in bounds]
+    inv_w, inv_h = F32(64) / (max_x - min_x), F32(48) / (max_y - min_y)
+    x, y, r = F32(x), F32(y), F32(r)
+    x_lo = max(0, int(np.floor((x - min_x - r) * inv_w)))
+    x_hi = min(63, int(np.ceil((x - min_x + r) * inv_w)))
+    y_lo = max(0, int(np.floor((y - min_y - r) * inv_h)))
+    y_hi = min(47, int(np.ceil((y - min_y + r) * inv_h)))
+    if x_lo >= 64 or x_hi < 0 or y_lo >= 48 or y_hi < 0:
+        return []
+    check = min_level > 0 or max_level >= 0
+    out = []
+    for ix in range(x_lo, x_hi + 1):
+        for iy in range(y_lo, y_hi + 1):
+            for i in grid.get(ix * 48 + iy, []):
+                o = kps_un["octave"][i]
+                if check and (o < min_level or (max_level >= 0 and o > max_level)):
+                    continue
+                if abs(kps_un["x"][i] - x) < r and abs(kps_un["y"][i] - y) < r:
+                    out.append(i)
+    return out
