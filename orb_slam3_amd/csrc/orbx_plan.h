@@ -59,14 +59,16 @@ struct LevelDesc {
   int patch_size;        // (int)(31 * scale)
   const Tap* xtab;       // [w + 38]
   const Tap* ytab;       // [h + 38]
-  // k_pyr_resize tiling: 256 x 16 destination tiles, source window staged in LDS
+  // k_pyr_resize: one column record per destination dword; the extents below describe the
+  // source window of a 256 x 16 destination tile (kept for a tile-staging variant of the kernel;
+  // the current kernel fetches its taps straight from the source plane and does not read them)
   const ColRec* colrec;  // [pstride / 4]
   const uint16_t* xblk;  // per 256-column block: lowest / highest source x touched
   const uint16_t* yblk;  // per 16-row block: lowest / highest source y touched
   const uint16_t* bcols; // dword columns that need the per-pixel tap path (borders)
   int n_bcols;
-  int rs_ls;             // LDS row stride (bytes) for this level's source windows
-  int rs_rows;           // LDS rows
+  int rs_ls;             // row stride (bytes) such a staged source window would need
+  int rs_rows;           // rows such a window would need
 };
 
 struct Plan {
