@@ -1001,4 +1001,172 @@ int orc_features_in_area(const float* bounds, const void* kpsUn28, const int* ce
   return found;
 }
 
+// ---- guided matching (the per-frame tracking matchers that walk the frame grid) ----------------
+// ORBmatcher::ComputeThreeMaxima, core/lib/ORB/matcher.cc:1925-1957.  sizes = bin sizes.
+void orc_three_maxima(const int* sizes, int L, int* ind) {
+  int max1 = 0, max2 = 0, max3 = 0;
+  int ind1 = -1, ind2 = -1, ind3 = -1;
+  for (int i = 0; i < L; ++i) {
+    const int s = sizes[i];
+    if (s > max1) {
+      max3 = max2; max2 = max1; max1 = s;
+      ind3 = ind2; ind2 = ind1; ind1 = i;
+    } else if (s > max2) {
+      max3 = max2; max2 = s;
+      ind3 = ind2; ind2 = i;
+    } else if (s > max3) {
+      max3 = s;
+      ind3 = i;
+    }
+  }
+  if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+  else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+  ind[0] = ind1; ind[1] = ind2; ind[2] = ind3;
+}
+
+namespace {
+const int kHistoLength = 30;   // ORBmatcher::HISTO_LENGTH, matcher.cc:36
+// rotation bin exactly as written at matcher.cc:694-700 (the product with 1/HISTO_LENGTH, not a
+// division by the bin width: bins 0..12 are the ones that occur)
+inline int rotationBin(float angle1, float angle2) {
+  const float factor = 1.0f / kHistoLength;
+  float rot = angle1 - angle2;
+  if (rot < 0.0) rot += 360.0f;
+  int bin = (int)std::round(rot * factor);
+  if (bin == kHistoLength) bin = 0;
+  return bin;
+}
+}  // namespace
+
+// ORBmatcher::SearchForInitialization, core/lib/ORB/matcher.cc:629-733, on flat arrays.
+// F2's grid is the CSR of orc_frame_grid (bounds, cellStart, entries over kps2Un).
+// prevMatched: n1 (x, y) pairs, updated as at :728-730.  matches12: n1 entries (-1 = none).
+int orc_search_for_initialization(const void* kps1Un28, const uint8_t* desc1, int n1,
+                                  const void* kps2Un28, const uint8_t* desc2, int n2,
+                                  const float* bounds2, const int* cellStart2, const int* entries2,
+                                  float* prevMatched, int windowSize, float nnratio,
+                                  int checkOrientation, int* matches12) {
+  const KeyPoint* K1 = (const KeyPoint*)kps1Un28;
+  const KeyPoint* K2 = (const KeyPoint*)kps2Un28;
+  const int TH_LOW = 50;
+  int nmatches = 0;
+  for (int i = 0; i < n1; ++i) matches12[i] = -1;
+  std::vector<std::vector<int>> rotHist(kHistoLength);
+  std::vector<int> matchedDistance(n2, INT_MAX), matches21(n2, -1);
+  std::vector<int> idx(std::max(n2, 1));
+  for (int i1 = 0; i1 < n1; ++i1) {
+    const int level1 = K1[i1].octave;
+    if (level1 > 0) continue;
+    const int found = orc_features_in_area(bounds2, kps2Un28, cellStart2, entries2, prevMatched[2 * i1],
+                                           prevMatched[2 * i1 + 1], (float)windowSize, level1, level1,
+                                           idx.data(), n2);
+    if (found == 0) continue;
+    int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+    for (int c = 0; c < found; ++c) {
+      const int i2 = idx[c];
+      const int dist = hamming256(desc1 + (size_t)i1 * 32, desc2 + (size_t)i2 * 32);
+      if (matchedDistance[i2] <= dist) continue;
+      if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+      else if (dist < bestDist2) { bestDist2 = dist; }
+    }
+    if (bestDist <= TH_LOW) {
+      if (bestDist < (float)bestDist2 * nnratio) {
+        if (matches21[bestIdx2] >= 0) { matches12[matches21[bestIdx2]] = -1; nmatches--; }
+        matches12[i1] = bestIdx2;
+        matches21[bestIdx2] = i1;
+        matchedDistance[bestIdx2] = bestDist;
+        nmatches++;
+        if (checkOrientation) rotHist[rotationBin(K1[i1].angle, K2[bestIdx2].angle)].push_back(i1);
+      }
+    }
+  }
+  if (checkOrientation) {
+    int sizes[kHistoLength], ind[3];
+    for (int i = 0; i < kHistoLength; ++i) sizes[i] = (int)rotHist[i].size();
+    orc_three_maxima(sizes, kHistoLength, ind);
+    for (int i = 0; i < kHistoLength; ++i) {
+      if (i == ind[0] || i == ind[1] || i == ind[2]) continue;
+      for (int idx1 : rotHist[i])
+        if (matches12[idx1] >= 0) { matches12[idx1] = -1; nmatches--; }
+    }
+  }
+  for (int i1 = 0; i1 < n1; ++i1)
+    if (matches12[i1] >= 0) { prevMatched[2 * i1] = K2[matches12[i1]].x; prevMatched[2 * i1 + 1] = K2[matches12[i1]].y; }
+  return nmatches;
+}
+
+// ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono), core/lib/ORB/matcher.cc:
+// 1591-1808, for a monocular or rectified current frame (Nleft == -1), on flat arrays.  The
+// projection of the last frame's map points (pose and camera model, :1614-1630) is the caller's:
+//   lastValid[i]   map point present and not an outlier (:1611-1613)
+//   uv[2i..]       its projection into the current frame; invz[i] = 1 / depth in the camera frame
+//   lastOctave[i], lastAngle[i]  octave / angle of the last frame's keypoint i (:1632-1635, :1691)
+//   lastDesc       the map point's representative descriptor (:1655), 32 bytes each
+//   lastObs[i]     pMP->Observations() > 0, consulted when a later candidate meets this match (:1665)
+// Current frame: undistorted keypoints, descriptors, mvuRight (may be NULL: monocular), the grid CSR
+// with its bounds, the scale factors, and state[i2] = 0 free / 1 holds a map point with
+// observations / 2 holds one without.  Outputs: assigned[i2] = last-frame index matched to
+// keypoint i2, -1 untouched, -2 cleared by the rotation check (:1799-1800).  Returns nmatches.
+int orc_search_by_projection_last(const uint8_t* lastValid, const float* uv, const float* invz,
+                                  const int* lastOctave, const float* lastAngle, const uint8_t* lastDesc,
+                                  const uint8_t* lastObs, int nLast, const void* kpsUn28,
+                                  const uint8_t* desc, const float* uRight, const uint8_t* state, int n,
+                                  const float* bounds, const int* cellStart, const int* entries,
+                                  const float* scaleFactors, float th, int forward, int backward, float mbf,
+                                  int checkOrientation, int* assigned) {
+  const KeyPoint* K = (const KeyPoint*)kpsUn28;
+  const int TH_HIGH = 100;
+  int nmatches = 0;
+  for (int i = 0; i < n; ++i) assigned[i] = -1;
+  // whether keypoint i2 currently holds a map point with observations: initial state, then
+  // whatever this loop assigned
+  std::vector<uint8_t> blocked(std::max(n, 1));
+  for (int i = 0; i < n; ++i) blocked[i] = state[i] == 1;
+  std::vector<std::vector<int>> rotHist(kHistoLength);
+  std::vector<int> idx(std::max(n, 1));
+  for (int i = 0; i < nLast; ++i) {
+    if (!lastValid[i]) continue;
+    const float invzc = invz[i];
+    if (invzc < 0) continue;
+    const float u = uv[2 * i], v = uv[2 * i + 1];
+    if (u < bounds[0] || u > bounds[1]) continue;
+    if (v < bounds[2] || v > bounds[3]) continue;
+    const int nLastOctave = lastOctave[i];
+    const float radius = th * scaleFactors[nLastOctave];
+    int found;
+    if (forward) found = orc_features_in_area(bounds, kpsUn28, cellStart, entries, u, v, radius, nLastOctave, -1, idx.data(), n);
+    else if (backward) found = orc_features_in_area(bounds, kpsUn28, cellStart, entries, u, v, radius, 0, nLastOctave, idx.data(), n);
+    else found = orc_features_in_area(bounds, kpsUn28, cellStart, entries, u, v, radius, nLastOctave - 1, nLastOctave + 1, idx.data(), n);
+    if (found == 0) continue;
+    int bestDist = 256, bestIdx2 = -1;
+    for (int c = 0; c < found; ++c) {
+      const int i2 = idx[c];
+      if (blocked[i2]) continue;
+      if (uRight && uRight[i2] > 0) {
+        const float ur = u - mbf * invzc;
+        const float er = std::fabs(ur - uRight[i2]);
+        if (er > radius) continue;
+      }
+      const int dist = hamming256(lastDesc + (size_t)i * 32, desc + (size_t)i2 * 32);
+      if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+    }
+    if (bestDist <= TH_HIGH) {
+      assigned[bestIdx2] = i;
+      blocked[bestIdx2] = lastObs[i] != 0;
+      nmatches++;
+      if (checkOrientation) rotHist[rotationBin(lastAngle[i], K[bestIdx2].angle)].push_back(bestIdx2);
+    }
+  }
+  if (checkOrientation) {
+    int sizes[kHistoLength], ind[3];
+    for (int i = 0; i < kHistoLength; ++i) sizes[i] = (int)rotHist[i].size();
+    orc_three_maxima(sizes, kHistoLength, ind);
+    for (int i = 0; i < kHistoLength; ++i) {
+      if (i == ind[0] || i == ind[1] || i == ind[2]) continue;
+      for (int i2 : rotHist[i]) { assigned[i2] = -2; nmatches--; }
+    }
+  }
+  return nmatches;
+}
+
 }  // extern "C"

@@ -416,3 +416,129 @@ def features_in_area(kps_un, grid, bounds, x, y, r, min_level, max_level):
                 if abs(kps_un["x"][i] - x) < r and abs(kps_un["y"][i] - y) < r:
                     out.append(i)
     return out
+
+
+# ---- guided matching: ORBmatcher::SearchForInitialization / SearchByProjection(Frame, LastFrame) ----
+HISTO_LENGTH = 30
+
+
+def three_maxima(sizes):
+    max1 = max2 = max3 = 0
+    i1 = i2 = i3 = -1
+    for i, s in enumerate(sizes):
+        if s > max1:
+            max3, max2, max1 = max2, max1, s
+            i3, i2, i1 = i2, i1, i
+        elif s > max2:
+            max3, max2 = max2, s
+            i3, i2 = i2, i
+        elif s > max3:
+            max3, i3 = s, i
+    if max2 < F32(0.1) * F32(max1):
+        i2 = i3 = -1
+    elif max3 < F32(0.1) * F32(max1):
+        i3 = -1
+    return i1, i2, i3
+
+
+def rotation_bin(a1, a2):
+    rot = F32(a1) - F32(a2)
+    if rot < 0:
+        rot = rot + F32(360.0)
+    b = int(c_round(rot * (F32(1.0) / F32(HISTO_LENGTH))))
+    return 0 if b == HISTO_LENGTH else b
+
+
+def search_for_initialization(k1, d1, k2, d2, grid2, bounds2, prev_matched, window, nnratio, check_orientation):
+    big = 2 ** 31 - 1
+    m12 = [-1] * len(k1)
+    m21 = [-1] * len(k2)
+    matched_dist = [big] * len(k2)
+    hist = [[] for _ in range(HISTO_LENGTH)]
+    nm = 0
+    pm = np.array(prev_matched, np.float32).copy()
+    for i1 in range(len(k1)):
+        if k1["octave"][i1] > 0:
+            continue
+        cand = features_in_area(k2, grid2, bounds2, pm[i1, 0], pm[i1, 1], window, 0, 0)
+        if not cand:
+            continue
+        best = best2 = big
+        bi = -1
+        for i2 in cand:
+            dist = hamming(d1[i1], d2[i2])
+            if matched_dist[i2] <= dist:
+                continue
+            if dist < best:
+                best2, best, bi = best, dist, i2
+            elif dist < best2:
+                best2 = dist
+        if best <= 50 and F32(best) < F32(best2) * F32(nnratio):
+            if m21[bi] >= 0:
+                m12[m21[bi]] = -1
+                nm -= 1
+            m12[i1], m21[bi], matched_dist[bi] = bi, i1, best
+            nm += 1
+            if check_orientation:
+                hist[rotation_bin(k1["angle"][i1], k2["angle"][bi])].append(i1)
+    if check_orientation:
+        keep = three_maxima([len(h) for h in hist])
+        for b in range(HISTO_LENGTH):
+            if b in keep:
+                continue
+            for i1 in hist[b]:
+                if m12[i1] >= 0:
+                    m12[i1] = -1
+                    nm -= 1
+    for i1 in range(len(k1)):
+        if m12[i1] >= 0:
+            pm[i1] = (k2["x"][m12[i1]], k2["y"][m12[i1]])
+    return nm, m12, pm
+
+
+def search_by_projection_last(last_valid, uv, invz, last_octave, last_angle, last_desc, last_obs, k, d, u_right,
+                              state, grid, bounds, scale, th, forward, backward, mbf, check_orientation):
+    assigned = [-1] * len(k)
+    blocked = [s == 1 for s in state]
+    hist = [[] for _ in range(HISTO_LENGTH)]
+    nm = 0
+    for i in range(len(last_valid)):
+        if not last_valid[i] or F32(invz[i]) < 0:
+            continue
+        u, v = F32(uv[i][0]), F32(uv[i][1])
+        if u < bounds[0] or u > bounds[1] or v < bounds[2] or v > bounds[3]:
+            continue
+        o = int(last_octave[i])
+        radius = F32(th) * scale[o]
+        if forward:
+            cand = features_in_area(k, grid, bounds, u, v, radius, o, -1)
+        elif backward:
+            cand = features_in_area(k, grid, bounds, u, v, radius, 0, o)
+        else:
+            cand = features_in_area(k, grid, bounds, u, v, radius, o - 1, o + 1)
+        best, bi = 256, -1
+        for i2 in cand:
+            if blocked[i2]:
+                continue
+            if u_right is not None and u_right[i2] > 0:
+                ur = u - F32(mbf) * F32(invz[i])
+                if abs(ur - u_right[i2]) > radius:
+                    continue
+            dist = hamming(last_desc[i], d[i2])
+            if dist < best:
+                best, bi = dist, i2
+        if bi >= 0 and best <= 100:
+            assigned[bi] = i
+            blocked[bi] = bool(last_obs[i])
+            nm += 1
+            if check_orientation:
+                hist[rotation_bin(last_angle[i], k["angle"][bi])].append(bi)
+    if check_orientation:
+        keep = three_maxima([len(h) for h in hist])
+        for b in range(HISTO_LENGTH):
+            if b in keep:
+                continue
+            for i2 in hist[b]:
+                assigned[i2] = -2
+                nm -= 1
+    return nm, assigned

@@ -51,6 +51,12 @@ def lib():
                                      C.c_void_p]
         L.orc_features_in_area.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                                            C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_three_maxima.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_search_for_initialization.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                                    C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                    C.c_int, C.c_float, C.c_int, C.c_void_p]
+        L.orc_search_by_projection_last.argtypes = [C.c_void_p] * 7 + [C.c_int] + [C.c_void_p] * 4 + [C.c_int] + \
+            [C.c_void_p] * 4 + [C.c_float, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]
         _lib = L
     return _lib
 
@@ -252,3 +258,50 @@ def features_in_area(bounds, kps_un, cs, ent, x, y, r, min_level, max_level, cap
     out = np.full(cap, -1, np.int32)
     n = lib().orc_features_in_area(_p(b), _p(kps_un), _p(cs), _p(ent), x, y, r, min_level, max_level, _p(out), cap)
     return n, out
+
+
+def three_maxima(sizes):
+    sizes = np.ascontiguousarray(sizes, np.int32)
+    ind = np.zeros(3, np.int32)
+    lib().orc_three_maxima(_p(sizes), len(sizes), _p(ind))
+    return tuple(int(v) for v in ind)
+
+
+def search_for_initialization(k1, d1, k2, d2, bounds2, cs2, ent2, prev_matched, window, nnratio=0.9,
+                              check_orientation=True):
+    k1 = np.ascontiguousarray(k1, KP)
+    k2 = np.ascontiguousarray(k2, KP)
+    d1 = np.ascontiguousarray(d1, np.uint8)
+    d2 = np.ascontiguousarray(d2, np.uint8)
+    ent2 = np.ascontiguousarray(ent2 if len(ent2) else np.zeros(1), np.int32)
+    pm = np.ascontiguousarray(prev_matched, np.float32).copy()
+    m12 = np.zeros(max(len(k1), 1), np.int32)
+    b = np.ascontiguousarray(bounds2, np.float32)
+    n = lib().orc_search_for_initialization(_p(k1), _p(d1), len(k1), _p(k2), _p(d2), len(k2), _p(b), _p(cs2),
+                                            _p(ent2), _p(pm), int(window), nnratio, int(check_orientation), _p(m12))
+    return n, m12[:len(k1)], pm
+
+
+def search_by_projection_last(last_valid, uv, invz, last_octave, last_angle, last_desc, last_obs, k, d, u_right,
+                              state, bounds, cs, ent, scale_factors, th, forward, backward, mbf,
+                              check_orientation=True):
+    lv = np.ascontiguousarray(last_valid, np.uint8)
+    uv = np.ascontiguousarray(uv, np.float32)
+    iz = np.ascontiguousarray(invz, np.float32)
+    lo = np.ascontiguousarray(last_octave, np.int32)
+    la = np.ascontiguousarray(last_angle, np.float32)
+    ld = np.ascontiguousarray(last_desc, np.uint8)
+    lobs = np.ascontiguousarray(last_obs, np.uint8)
+    k = np.ascontiguousarray(k, KP)
+    d = np.ascontiguousarray(d, np.uint8)
+    ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+    st = np.ascontiguousarray(state, np.uint8)
+    ent = np.ascontiguousarray(ent if len(ent) else np.zeros(1), np.int32)
+    b = np.ascontiguousarray(bounds, np.float32)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    out = np.zeros(max(len(k), 1), np.int32)
+    n = lib().orc_search_by_projection_last(_p(lv), _p(uv), _p(iz), _p(lo), _p(la), _p(ld), _p(lobs), len(lv),
+                                            _p(k), _p(d), _p(ur) if ur is not None else None, _p(st), len(k),
+                                            _p(b), _p(cs), _p(ent), _p(sf), th, int(forward), int(backward), mbf,
+                                            int(check_orientation), _p(out))
+    return n, out[:len(k)]

@@ -142,3 +142,63 @@ def test_undistortion_grid_and_window_queries(oracle):
         lo, hi = int(rng.choice([-1, 0, 2])), int(rng.choice([-1, 3, 7]))
         n, out = oracle.features_in_area(b, un, cs, ent, x, y, r, lo, hi, cap=600)
         assert out[:n].tolist() == S.features_in_area(un, grid, b, x, y, r, lo, hi)
+
+
+def _two_frames(oracle, shift=6):
+    import orb_slam3_amd as orbx
+    params = (500, 1.2, 5, 20, 7)
+    wide = orbx.textured_frame(41, 400 + shift, 300)
+    a = np.ascontiguousarray(wide[:, shift:])
+    b = np.ascontiguousarray(wide[:, :400])           # b(x) = a(x - shift): content moves right
+    ea, eb = oracle.Extractor(*params), oracle.Extractor(*params)
+    _, _, ka, da = ea.extract(a, (0, 0))
+    _, _, kb, db = eb.extract(b, (0, 0))
+    bounds = oracle.image_bounds(None, 400, 300)
+    un_b, cs, ent = oracle.frame_grid(None, bounds, kb)
+    return params, ka, da, un_b, db, bounds, cs, ent
+
+
+def test_three_maxima(oracle):
+    rng = np.random.default_rng(1)
+    for _ in range(200):
+        sizes = rng.integers(0, rng.choice([3, 12, 200]), 30)
+        assert oracle.three_maxima(sizes) == S.three_maxima(sizes.tolist())
+    assert oracle.three_maxima([0] * 30) == (-1, -1, -1)
+    assert oracle.three_maxima([5] + [0] * 29) == (0, -1, -1)
+
+
+def test_search_for_initialization(oracle):
+    params, ka, da, kb, db, bounds, cs, ent = _two_frames(oracle)
+    prev = np.stack([ka["x"], ka["y"]], 1)
+    grid = S.frame_grid(kb, bounds)
+    for ori in (True, False):
+        n, m12, pm = oracle.search_for_initialization(ka, da, kb, db, bounds, cs, ent, prev, 100, 0.9, ori)
+        sn, sm12, spm = S.search_for_initialization(ka, da, kb, db, grid, bounds, prev, 100, 0.9, ori)
+        assert n == sn and m12.tolist() == sm12 and np.array_equal(pm, spm)
+        assert n > 30
+        ok = m12 >= 0
+        assert (np.abs((kb["x"][m12[ok]] - ka["x"][ok]) - 6) <= 2).mean() > 0.9   # the shift is found
+
+
+def test_search_by_projection_last(oracle):
+    params, ka, da, kb, db, bounds, cs, ent = _two_frames(oracle)
+    rng = np.random.default_rng(5)
+    n_last = len(ka)
+    scale, _ = S.level_tables(params[2], params[1])
+    uv = np.stack([ka["x"] + 6 + rng.uniform(-2, 2, n_last), ka["y"] + rng.uniform(-2, 2, n_last)], 1).astype(np.float32)
+    uv[::17] += 500                                            # some projections leave the image
+    invz = rng.uniform(0.05, 1.0, n_last).astype(np.float32)
+    invz[::23] = -0.1                                          # behind the camera
+    valid = (rng.random(n_last) < 0.9).astype(np.uint8)
+    obs = (rng.random(n_last) < 0.7).astype(np.uint8)          # temporal points have no observations
+    state = rng.choice([0, 0, 0, 1, 2], len(kb)).astype(np.uint8)
+    u_right = np.where(rng.random(len(kb)) < 0.5, kb["x"] - rng.uniform(1, 30, len(kb)), -1).astype(np.float32)
+    grid = S.frame_grid(kb, bounds)
+    for forward, backward, ur, th in [(0, 0, None, 15.0), (0, 0, u_right, 7.0), (1, 0, u_right, 15.0), (0, 1, None, 15.0)]:
+        n, asg = oracle.search_by_projection_last(valid, uv, invz, ka["octave"], ka["angle"], da, obs, kb, db, ur,
+                                                  state, bounds, cs, ent, np.array(scale, np.float32), th,
+                                                  forward, backward, 40.0, True)
+        sn, sasg = S.search_by_projection_last(valid, uv, invz, ka["octave"], ka["angle"], da, obs, kb, db, ur,
+                                               state, grid, bounds, scale, th, forward, backward, 40.0, True)
+        assert n == sn and asg.tolist() == sasg, (forward, backward)
+        assert (asg >= 0).sum() > 20
