@@ -1,3 +1,4 @@
+"""Latency of one single-frame extraction split into its parts (device work, download, full call)."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
