@@ -542,3 +542,129 @@ def search_by_projection_last(last_valid, uv, invz, last_octave, last_angle, las
                 assigned[i2] = -2
                 nm -= 1
     return nm, assigned
+
+
+# ---- the guided matchers as rounds of independent decisions (the form a GPU can run) ---------------
+# Both reference loops are greedy over the query index.  What a query may take depends only on
+# what queries with a LOWER index took, so the loop equals the unique fixed point of "every query
+# decides from the claims of the lower-indexed queries of the previous round"; iterating from "no
+# claims" reaches it after at most (longest dependency chain + 1) rounds.
+def rounds_search_by_projection_last(last_valid, uv, invz, last_octave, last_angle, last_desc, last_obs, k, d,
+                                     u_right, state, grid, bounds, scale, th, forward, backward, mbf,
+                                     check_orientation):
+    n_last, n = len(last_valid), len(k)
+    inf = n_last + 1
+    cand = []
+    for i in range(n_last):                       # window walk + distances: independent per query
+        lst = []
+        u, v = F32(uv[i][0]), F32(uv[i][1])
+        ok = last_valid[i] and not F32(invz[i]) < 0 and bounds[0] <= u <= bounds[1] and bounds[2] <= v <= bounds[3]
+        if ok:
+            o = int(last_octave[i])
+            radius = F32(th) * scale[o]
+            lo, hi = (o, -1) if forward else ((0, o) if backward else (o - 1, o + 1))
+            for i2 in features_in_area(k, grid, bounds, u, v, radius, lo, hi):
+                if u_right is not None and u_right[i2] > 0:
+                    if abs((u - F32(mbf) * F32(invz[i])) - u_right[i2]) > radius:
+                        continue
+                lst.append((i2, hamming(last_desc[i], d[i2])))
+        cand.append(lst)
+    block_time = [0 if s == 1 else inf for s in state]   # index of the first blocking claim
+    choice = [-1] * n_last
+    rounds = 0
+    while True:
+        rounds += 1
+        new_choice = []
+        for i in range(n_last):
+            best, bi = 256, -1
+            for i2, dist in cand[i]:
+                if block_time[i2] < i or (block_time[i2] == 0 and state[i2] == 1):
+                    continue
+                if dist < best:
+                    best, bi = dist, i2
+            new_choice.append(bi if best <= 100 else -1)
+        new_block = [0 if s == 1 else inf for s in state]
+        for i, c in enumerate(new_choice):
+            if c >= 0 and last_obs[i]:
+                new_block[c] = min(new_block[c], i)
+        if new_choice == choice and new_block == block_time:
+            break
+        choice, block_time = new_choice, new_block
+    assigned = [-1] * n
+    nm = 0
+    hist = [[] for _ in range(HISTO_LENGTH)]
+    for i, c in enumerate(choice):
+        if c >= 0:
+            assigned[c] = i                      # ascending i: the last claim stays
+            nm += 1
+            if check_orientation:
+                hist[rotation_bin(last_angle[i], k["angle"][c])].append(c)
+    if check_orientation:
+        keep = three_maxima([len(h) for h in hist])
+        for b in range(HISTO_LENGTH):
+            if b not in keep:
+                for c in hist[b]:
+                    assigned[c] = -2
+                    nm -= 1
+    return nm, assigned, rounds
+
+
+def rounds_search_for_initialization(k1, d1, k2, d2, grid2, bounds2, prev_matched, window, nnratio,
+                                     check_orientation):
+    n1, n2 = len(k1), len(k2)
+    big = 2 ** 31 - 1
+    pm = np.array(prev_matched, np.float32)
+    cand = []
+    for i1 in range(n1):
+        lst = []
+        if k1["octave"][i1] <= 0:
+            for i2 in features_in_area(k2, grid2, bounds2, pm[i1, 0], pm[i1, 1], window, 0, 0):
+                lst.append((i2, hamming(d1[i1], d2[i2])))
+        cand.append(lst)
+    claims = [None] * n1                          # (keypoint, distance) accepted by query i1
+    rounds = 0
+    while True:
+        rounds += 1
+        # matched distance of a keypoint as query i1 sees it = smallest distance among the claims of
+        # lower-indexed queries (every accepted claim undercuts the one before it)
+        per_kp = [[] for _ in range(n2)]
+        for j, c in enumerate(claims):
+            if c is not None:
+                per_kp[c[0]].append((j, c[1]))
+        new_claims = []
+        for i1 in range(n1):
+            best = best2 = big
+            bi = -1
+            for i2, dist in cand[i1]:
+                seen = min([dd for j, dd in per_kp[i2] if j < i1], default=big)
+                if seen <= dist:
+                    continue
+                if dist < best:
+                    best2, best, bi = best, dist, i2
+                elif dist < best2:
+                    best2 = dist
+            ok = bi >= 0 and best <= 50 and F32(best) < F32(best2) * F32(nnratio)
+            new_claims.append((bi, best) if ok else None)
+        if new_claims == claims:
+            break
+        claims = new_claims
+    m12 = [-1] * n1
+    owner = {}
+    hist = [[] for _ in range(HISTO_LENGTH)]
+    for i1, c in enumerate(claims):
+        if c is not None:
+            owner[c[0]] = i1                      # ascending i1: the last claimant owns the keypoint
+            if check_orientation:
+                hist[rotation_bin(k1["angle"][i1], k2["angle"][c[0]])].append(i1)
+    for kp, i1 in owner.items():
+        m12[i1] = kp
+    nm = len(owner)
+    if check_orientation:
+        keep = three_maxima([len(h) for h in hist])
+        for b in range(HISTO_LENGTH):
+            if b not in keep:
+                for i1 in hist[b]:
+                    if m12[i1] >= 0:
+                        m12[i1] = -1
+                        nm -= 1
+    return nm, m12, rounds

@@ -202,3 +202,34 @@ def test_search_by_projection_last(oracle):
                                                state, grid, bounds, scale, th, forward, backward, 40.0, True)
         assert n == sn and asg.tolist() == sasg, (forward, backward)
         assert (asg >= 0).sum() > 20
+
+
+def test_guided_matchers_as_rounds_equal_the_greedy_loops(oracle):
+    """The data-parallel formulation planned for the device (rounds of independent decisions that
+    only look at lower-indexed queries' claims) reproduces the reference's sequential loops, in a
+    handful of rounds."""
+    params, ka, da, kb, db, bounds, cs, ent = _two_frames(oracle)
+    rng = np.random.default_rng(6)
+    n_last = len(ka)
+    scale, _ = S.level_tables(params[2], params[1])
+    grid = S.frame_grid(kb, bounds)
+    uv = np.stack([ka["x"] + 6 + rng.uniform(-3, 3, n_last), ka["y"] + rng.uniform(-3, 3, n_last)], 1).astype(np.float32)
+    invz = rng.uniform(0.05, 1.0, n_last).astype(np.float32)
+    valid = np.ones(n_last, np.uint8)
+    state = rng.choice([0, 0, 0, 0, 1, 2], len(kb)).astype(np.uint8)
+    worst = 0
+    for obs_p, th in [(1.0, 15.0), (0.6, 25.0), (0.0, 15.0)]:
+        obs = (rng.random(n_last) < obs_p).astype(np.uint8)
+        n, asg = oracle.search_by_projection_last(valid, uv, invz, ka["octave"], ka["angle"], da, obs, kb, db, None,
+                                                  state, bounds, cs, ent, np.array(scale, np.float32), th, 0, 0, 40.0, True)
+        rn, rasg, rounds = S.rounds_search_by_projection_last(valid, uv, invz, ka["octave"], ka["angle"], da, obs, kb,
+                                                              db, None, state, grid, bounds, scale, th, 0, 0, 40.0, True)
+        assert (n, asg.tolist()) == (rn, rasg)
+        worst = max(worst, rounds)
+    prev = np.stack([ka["x"], ka["y"]], 1)
+    for window in (30, 100):
+        n, m12, _ = oracle.search_for_initialization(ka, da, kb, db, bounds, cs, ent, prev, window, 0.9, True)
+        rn, rm12, rounds = S.rounds_search_for_initialization(ka, da, kb, db, grid, bounds, prev, window, 0.9, True)
+        assert (n, m12.tolist()) == (rn, rm12)
+        worst = max(worst, rounds)
+    assert worst <= 8, worst
