@@ -13,7 +13,10 @@
 // GaussianBlur 7x7 sigma 2 fixed-point, fastAtan2, cvRound) are restated from
 // OpenCV 4.x's published algorithms.  What pins this file: the in-tree data
 // (BRIEF pattern, constants), the derived known answers (per-level quotas,
-// umax, level sizes, blur kernel) and self-consistency tests under tests/.
+// umax, level sizes, blur kernel), self-consistency tests under tests/, and a
+// second restatement written separately in numpy (tests/numpy_spec.py) that
+// must agree with this one bit for bit.  tools/ref_orb_opencv.cc compares the
+// exported primitives with a real OpenCV wherever one is installed.
 //
 // Floating-point canon (build with -ffp-contract=off):
 //   * no fused multiply-add anywhere;
