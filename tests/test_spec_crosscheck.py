@@ -233,3 +233,23 @@ def test_guided_matchers_as_rounds_equal_the_greedy_loops(oracle):
         assert (n, m12.tolist()) == (rn, rm12)
         worst = max(worst, rounds)
     assert worst <= 8, worst
+
+
+@pytest.mark.parametrize("w,h,params", [(180, 140, (200, 1.1, 3, 20, 7)), (231, 173, (300, 1.5, 3, 25, 5)),
+                                        (256, 200, (250, 2.0, 2, 12, 12)), (199, 151, (150, 1.2, 4, 40, 10))])
+def test_other_sizes_and_parameters(oracle, w, h, params):
+    """Pyramid, blur and per-cell candidates for other scale factors, thresholds and odd sizes."""
+    import orb_slam3_amd as orbx
+    img = orbx.textured_frame(w + h, w, h)
+    e = oracle.Extractor(*params)
+    st, _, k, _ = e.extract(img, (0, 0))
+    assert st == 0 and len(k) > 20
+    levels, padded = S.build_pyramid(img, params[2], params[1])
+    for l in range(params[2]):
+        lw, lh, _ = e.level_dims(l)
+        assert np.array_equal(e.padded(l)[:, :lw + 38], padded[l]), l
+        b = e.blurred(l)
+        if b is not None:
+            assert np.array_equal(b, S.gaussian7(levels[l])), l
+        want = S.level_candidates(padded[l], lw, lh, params[3], params[4])
+        assert [tuple(r) for r in e.candidates(l).tolist()] == want, l
