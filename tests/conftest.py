@@ -11,6 +11,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "needs_real_device: cannot run under the kernel host simulation (sizes, or a binary linked to the real library)")
 
 
 def _has_gpu():
@@ -23,9 +24,42 @@ def _has_gpu():
 
 HAS_GPU = _has_gpu()
 
+# ORBX_HOSTSIM=1: run the GPU-marked tests against tests/hostsim (the library's kernels
+# compiled for the host and executed thread by thread with guarded memory).  This checks
+# kernel addressing and logic where there is no GPU; it is never what the package loads by
+# itself and it is not a parity result for the GPU.
+HOSTSIM = os.environ.get("ORBX_HOSTSIM") == "1"
+
+
+def _load_hostsim():
+    import ctypes
+    sim_dir = os.path.join(ROOT, "tests", "hostsim")
+    subprocess.check_call(["make", "-C", sim_dir, "-j8"], stdout=subprocess.DEVNULL)
+    from orb_slam3_amd import _lib
+    handle = ctypes.CDLL(os.path.join(sim_dir, "_build", "liborbx_hostsim.so"), mode=ctypes.RTLD_LOCAL)
+    for name, (res, args) in _lib.SIGNATURES.items():
+        fn = getattr(handle, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib._lib = handle
+
+
+if HOSTSIM and not HAS_GPU:
+    _load_hostsim()
+
+# where tests that pass device pointers put their tensors: under the host simulation device
+# memory is host memory
+TORCH_DEVICE = "cuda" if HAS_GPU else "cpu"
+
 
 def pytest_collection_modifyitems(config, items):
     if HAS_GPU:
+        return
+    if HOSTSIM:
+        skip = pytest.mark.skip(reason="needs a real device")
+        for item in items:
+            if "gpu" in item.keywords and "needs_real_device" in item.keywords:
+                item.add_marker(skip)
         return
     skip = pytest.mark.skip(reason="no GPU in this container")
     for item in items:

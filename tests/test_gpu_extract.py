@@ -185,10 +185,11 @@ def test_batch_position_independence_and_idempotence():
 
 def test_device_resident_batch_matches_host_batch():
     import torch
+    from tests.conftest import TORCH_DEVICE
     frames = np.stack([orbx.textured_frame(40 + i, 752, 480) for i in range(24)])
     ex = orbx.ORBextractor(1000, 1.2, 8, 20, 7, max_batch=24)
     host = ex.extract_batch(frames, (0, 1000))
-    d = torch.from_numpy(frames).cuda()
+    d = torch.from_numpy(frames).to(TORCH_DEVICE)
     ex.extract_batch_device(d.data_ptr(), 24, 752, 480, 752, (0, 1000))
     ex.sync()
     for f in range(24):

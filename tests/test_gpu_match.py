@@ -54,27 +54,29 @@ def test_knn2_device_sharded_merge(oracle):
     import ctypes as C
     import torch
     from orb_slam3_amd._lib import lib, check
+    from tests.conftest import TORCH_DEVICE
     rng = np.random.default_rng(11)
     q, t = planted(rng, 777, 40000)
     ridx, rdist = oracle.knn2(q, t)
-    dq = torch.from_numpy(q).cuda()
-    dt = torch.from_numpy(t).cuda()
+    dq = torch.from_numpy(q).to(TORCH_DEVICE)
+    dt = torch.from_numpy(t).to(TORCH_DEVICE)
     for shards in (1, 2, 4, 8):
         bounds = np.linspace(0, len(t), shards + 1).astype(int)
         bounds = (bounds // 8) * 8
         bounds[-1] = len(t)
-        pidx = torch.empty((shards, len(q), 2), dtype=torch.int32, device="cuda")
-        pdst = torch.empty((shards, len(q), 2), dtype=torch.int16, device="cuda")
+        pidx = torch.empty((shards, len(q), 2), dtype=torch.int32, device=TORCH_DEVICE)
+        pdst = torch.empty((shards, len(q), 2), dtype=torch.int16, device=TORCH_DEVICE)
         for s in range(shards):
             sl = dt[bounds[s]:bounds[s + 1]]
             check(lib().orbx_knn2_device(C.c_void_p(dq.data_ptr()), len(q), C.c_void_p(sl.data_ptr()),
                                          sl.shape[0], int(bounds[s]), C.c_void_p(pidx[s].data_ptr()),
                                          C.c_void_p(pdst[s].data_ptr()), None))
-        oi = torch.empty((len(q), 2), dtype=torch.int32, device="cuda")
-        od = torch.empty((len(q), 2), dtype=torch.int16, device="cuda")
+        oi = torch.empty((len(q), 2), dtype=torch.int32, device=TORCH_DEVICE)
+        od = torch.empty((len(q), 2), dtype=torch.int16, device=TORCH_DEVICE)
         check(lib().orbx_top2_merge_device(C.c_void_p(pidx.data_ptr()), C.c_void_p(pdst.data_ptr()), shards,
                                            len(q), C.c_void_p(oi.data_ptr()), C.c_void_p(od.data_ptr()), None))
-        torch.cuda.synchronize()
+        if TORCH_DEVICE == "cuda":
+            torch.cuda.synchronize()
         assert np.array_equal(oi.cpu().numpy().view(np.uint32), ridx), shards
         assert np.array_equal(od.cpu().numpy().view(np.uint16), rdist), shards
 
@@ -137,6 +139,7 @@ def test_fisheye_config_knn_on_lapping_subsets(oracle):
     assert orbx.ratio_test(idx, dist).sum() > 50
 
 
+@pytest.mark.needs_real_device
 def test_knn2_large_properties():
     """200k queries x 2M train rows (4e11 pairs; the oracle cannot run this): size-independent
     properties - sharded == unsharded, planted rows found at distance 0 at their lowest index,

@@ -125,6 +125,7 @@ def test_stereo_argument_errors():
     orbx.compute_stereo_matches(a, b, MBF, MB)
 
 
+@pytest.mark.needs_real_device
 def test_cv_adaptor_binary():
     """include/orbx_cv.hpp (ORBextractor / DescriptorDistance / ComputeStereoMatches / KnnMatch2
     with OpenCV-style types) gives the same bytes as the C ABI it wraps.  The binary is built by

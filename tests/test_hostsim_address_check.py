@@ -1,0 +1,31 @@
+"""Address and convergence check of the kernels without a GPU.
+
+tests/hostsim compiles the library's .hip sources for the host and runs every kernel thread
+by thread: device allocations and dynamic LDS sit against guard pages, so an out-of-bounds
+access of any kernel stops the run; lanes of a wave that meet at different cross-lane
+operations are reported; and because the simulated kernels execute the same source, their
+outputs can be compared with the CPU oracle.  Here the whole GPU-marked suite is run against
+that build, once with the guard page behind every allocation and once in front of it.
+
+This is a check of the kernels' addressing and logic.  It is not a GPU parity result (the
+GPU tests proper are the ones marked `gpu`, run on the MI355X) and nothing in the package
+loads the simulation build.
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("guard", ["end", "start"])
+def test_gpu_suite_under_host_simulation(guard):
+    env = dict(os.environ, ORBX_HOSTSIM="1", HOSTSIM_GUARD=guard)
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests"), "-m", "gpu", "-q", "-x",
+                          "-p", "no:faulthandler", "-p", "no:cacheprovider"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    tail = (out.stdout + out.stderr)[-3000:]
+    assert out.returncode == 0, tail
+    assert " passed" in out.stdout and " failed" not in out.stdout, tail
