@@ -259,6 +259,44 @@ int orbx_frame_grid_download(orbx_extractor* ex, int frame, orbx_keypoint* kps_u
 int orbx_features_in_area(orbx_extractor* ex, int frame, const float* queries, int n_queries,
                           int32_t* indices, int per_query_cap, int32_t* counts);
 
+/* ---- guided matchers on a frame with a device-resident grid ------------------ */
+/* ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono),
+ * core/lib/ORB/matcher.cc:1591-1808, monocular / rectified case (Nleft == -1).
+ * The current frame is frame `frame` of the last extraction + grid call on
+ * `cur` (undistorted keypoints, descriptors and grid are read where they lie in
+ * device memory).  The last frame arrives as flat host arrays, one entry per
+ * keypoint of the last frame; projecting its map points with the current pose
+ * (:1614-1630) is the caller's:
+ *   last_valid[i]   a map point exists and is not an outlier (:1607-1613)
+ *   uv[2i], uv[2i+1]  its projection into the current frame; invz[i] = 1 / depth
+ *   last_octave[i], last_angle[i]  of the last frame's keypoint i (:1632, :1691)
+ *   last_desc       the map point's descriptor (:1655), 32 bytes each
+ *   last_obs[i]     pMP->Observations() > 0 (what :1665 finds once it is assigned)
+ * u_right: the current frame's mvuRight (n entries) or NULL (monocular).
+ * state:   per current keypoint 0 = no map point, 1 = holds one with
+ *          observations, 2 = holds one without; NULL = all 0.
+ * forward / backward: the flags of :1621-1622.  th, mbf as in the reference.
+ * assigned[i2] (cap entries, n used) = index of the last-frame keypoint whose
+ * map point keypoint i2 received, -1 = untouched, -2 = set and cleared again by
+ * the rotation check (:1799-1800).  *nmatches = the reference's return value.
+ * rounds (may be NULL) = decision rounds the device took.  Blocks. */
+int orbx_search_by_projection_last(orbx_extractor* cur, int frame, int n_last, const uint8_t* last_valid,
+                                   const float* uv, const float* invz, const int32_t* last_octave,
+                                   const float* last_angle, const uint8_t* last_desc,
+                                   const uint8_t* last_obs, const float* u_right, const uint8_t* state,
+                                   float th, int forward, int backward, float mbf, int check_orientation,
+                                   int32_t* assigned, int cap, int* n_out, int* nmatches, int* rounds);
+/* ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12,
+ * windowSize), core/lib/ORB/matcher.cc:629-733.  F2 is frame `frame2` of the
+ * last extraction + grid call on `f2`; F1 arrives as host arrays (mvKeysUn and
+ * descriptors, n1 entries).  prev_matched: n1 (x, y) pairs, updated as at
+ * :728-730.  matches12: n1 entries, -1 = none.  nnratio and check_orientation
+ * are the matcher's constructor arguments.  *nmatches = the return value. */
+int orbx_search_for_initialization(orbx_extractor* f2, int frame2, int n1, const orbx_keypoint* kps1_un,
+                                   const uint8_t* desc1, float* prev_matched, int window_size,
+                                   float nnratio, int check_orientation, int32_t* matches12, int* nmatches,
+                                   int* rounds);
+
 /* ---- synthetic input ------------------------------------------------------- */
 /* Deterministic textured test frame (PCG32-seeded rectangles + noise + 3x3
  * box blur), written to dst (height rows of stride bytes).  Host only. */

@@ -94,6 +94,11 @@ SIGNATURES = {
     "orbx_frame_grid_results_device": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _i32p]),
     "orbx_frame_grid_download": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int, _i32p]),
     "orbx_features_in_area": (C.c_int, [_P, C.c_int, _f32p, C.c_int, _P, C.c_int, _P]),
+    "orbx_search_by_projection_last": (C.c_int, [_P, C.c_int, C.c_int, _P, _f32p, _f32p, _i32p, _f32p, _P, _P, _P, _P,
+                                                 C.c_float, C.c_int, C.c_int, C.c_float, C.c_int, _P, C.c_int,
+                                                 _i32p, _i32p, _i32p]),
+    "orbx_search_for_initialization": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _f32p, C.c_int, C.c_float,
+                                                 C.c_int, _P, _i32p, _i32p]),
     "orbx_synth_frame": (C.c_int, [C.c_uint32, C.c_int, C.c_int, C.c_int, _P]),
 }
 

@@ -46,6 +46,21 @@ void launch_features_in_area(const float* d_kpsUn, int cap, const int* d_cellSta
                              int frame, const float* bounds, const float* d_queries, int nq, int* d_out,
                              int percap, int* d_counts, hipStream_t s);
 int launch_debug_sort(uint64_t* d_data, int n, hipStream_t s);
+size_t projection_work_ints(int nLast, int n);
+size_t init_work_ints(int n1, int n2);
+void launch_search_by_projection_last(const uint8_t* d_lastValid, const float* d_uv, const float* d_invz,
+                                      const int* d_lastOctave, const float* d_lastAngle, const uint8_t* d_lastDesc,
+                                      const uint8_t* d_lastObs, int nLast, const float* d_kpsUn,
+                                      const uint8_t* d_desc, const float* d_uRight, const uint8_t* d_state, int n,
+                                      const int* d_cellStart, const int* d_entries, const float* bounds,
+                                      const float* scaleFactors, int nlevels, float th, int forward, int backward,
+                                      float mbf, int checkOrientation, int* d_work, int* d_assigned, int* d_summary,
+                                      hipStream_t s);
+void launch_search_for_initialization(const float* d_kps1Un, const uint8_t* d_desc1, int n1, float* d_prevMatched,
+                                      const float* d_kps2Un, const uint8_t* d_desc2, int n2,
+                                      const int* d_cellStart2, const int* d_entries2, const float* bounds2,
+                                      float window, float nnratio, int checkOrientation, int* d_work,
+                                      int* d_matches12, int* d_summary, hipStream_t s);
 }  // namespace orbx
 
 using orbx::LevelDesc;
@@ -961,6 +976,132 @@ int orbx_features_in_area(orbx_extractor* ex, int frame, const float* queries, i
   if (dout) (void)hipFreeAsync(dout, s);
   if (dcnt) (void)hipFreeAsync(dcnt, s);
   if (e != hipSuccess) { last_hip_error = e; return ORBX_ERR_HIP; }
+  return ORBX_OK;
+}
+
+// ---- guided matchers on a frame with a device-resident grid ------------------------------------
+namespace {
+// carves one stream-ordered allocation into 256-byte aligned pieces
+struct Carver {
+  size_t total = 0;
+  size_t add(size_t bytes) { const size_t at = total; total += (bytes + 255) / 256 * 256; return at; }
+};
+const int kGuidedMaxQueries = 1 << 20;
+}  // namespace
+
+int orbx_search_by_projection_last(orbx_extractor* cur, int frame, int n_last, const uint8_t* last_valid,
+                                   const float* uv, const float* invz, const int32_t* last_octave,
+                                   const float* last_angle, const uint8_t* last_desc, const uint8_t* last_obs,
+                                   const float* u_right, const uint8_t* state, float th, int forward,
+                                   int backward, float mbf, int check_orientation, int32_t* assigned, int cap,
+                                   int* n_out, int* nmatches, int* rounds) {
+  orbx_extractor* ex = cur;
+  if (!ex || !ex->planned || !ex->d_kpsUn || frame < 0 || frame >= ex->gridFrames || n_last < 0 ||
+      n_last > kGuidedMaxQueries || cap < 0 || !nmatches)
+    return ORBX_ERR_BAD_ARG;
+  if (n_last > 0 && (!last_valid || !uv || !invz || !last_octave || !last_angle || !last_desc || !last_obs))
+    return ORBX_ERR_BAD_ARG;
+  for (int i = 0; i < n_last; ++i)
+    if (last_valid[i] && (last_octave[i] < 0 || last_octave[i] >= ex->prm.nlevels)) return ORBX_ERR_BAD_ARG;
+  if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  auto& last_hip_error = ex->last_hip_error;
+  hipStream_t s = ex->stream;
+  int n = 0;
+  HIP_TRY(hipMemcpyAsync(&n, ex->d_n + frame, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (n_out) *n_out = n;
+  *nmatches = 0;
+  if (rounds) *rounds = 0;
+  if (n > cap) return ORBX_ERR_CAPACITY;
+  if (n > 0 && !assigned) return ORBX_ERR_BAD_ARG;
+  if (n == 0) return ORBX_OK;
+  if (n_last == 0) {
+    for (int i = 0; i < n; ++i) assigned[i] = -1;
+    return ORBX_OK;
+  }
+  const size_t nl = (size_t)n_last, nn = (size_t)n;
+  Carver c;
+  const size_t oValid = c.add(nl), oUv = c.add(nl * 8), oInvz = c.add(nl * 4), oOct = c.add(nl * 4),
+               oAng = c.add(nl * 4), oDesc = c.add(nl * 32), oObs = c.add(nl), oUr = c.add(nn * 4),
+               oState = c.add(nn), oWork = c.add(orbx::projection_work_ints(n_last, n) * 4),
+               oAsg = c.add(nn * 4), oSum = c.add(8);
+  uint8_t* d = nullptr;
+  hipError_t e = hipMallocAsync((void**)&d, c.total, s);
+  if (e != hipSuccess) { last_hip_error = e; return ORBX_ERR_HIP; }
+  auto up = [&](size_t off, const void* src, size_t bytes) {
+    if (e == hipSuccess) e = hipMemcpyAsync(d + off, src, bytes, hipMemcpyHostToDevice, s);
+  };
+  up(oValid, last_valid, nl); up(oUv, uv, nl * 8); up(oInvz, invz, nl * 4); up(oOct, last_octave, nl * 4);
+  up(oAng, last_angle, nl * 4); up(oDesc, last_desc, nl * 32); up(oObs, last_obs, nl);
+  if (u_right) up(oUr, u_right, nn * 4);
+  if (state) up(oState, state, nn);
+  int sum[2] = {0, 0};
+  if (e == hipSuccess) {
+    const size_t base = (size_t)frame * ex->hp.kp_cap;
+    orbx::launch_search_by_projection_last(
+        d + oValid, (const float*)(d + oUv), (const float*)(d + oInvz), (const int*)(d + oOct),
+        (const float*)(d + oAng), d + oDesc, d + oObs, n_last, ex->d_kpsUn + base * 7, ex->d_desc + base * 32,
+        u_right ? (const float*)(d + oUr) : nullptr, state ? d + oState : nullptr, n,
+        ex->d_cellStart + (size_t)frame * (ORBX_GRID_CELLS + 1), ex->d_cellEntries + base, ex->gridBounds,
+        ex->scale.data(), ex->prm.nlevels, th, forward != 0, backward != 0, mbf, check_orientation != 0,
+        (int*)(d + oWork), (int*)(d + oAsg), (int*)(d + oSum), s);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(assigned, d + oAsg, nn * 4, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(sum, d + oSum, 8, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFreeAsync(d, s);
+  if (e != hipSuccess) { last_hip_error = e; return ORBX_ERR_HIP; }
+  *nmatches = sum[0];
+  if (rounds) *rounds = sum[1];
+  return ORBX_OK;
+}
+
+int orbx_search_for_initialization(orbx_extractor* f2, int frame2, int n1, const orbx_keypoint* kps1_un,
+                                   const uint8_t* desc1, float* prev_matched, int window_size, float nnratio,
+                                   int check_orientation, int32_t* matches12, int* nmatches, int* rounds) {
+  orbx_extractor* ex = f2;
+  if (!ex || !ex->planned || !ex->d_kpsUn || frame2 < 0 || frame2 >= ex->gridFrames || n1 < 0 ||
+      n1 > kGuidedMaxQueries || !nmatches)
+    return ORBX_ERR_BAD_ARG;
+  if (n1 > 0 && (!kps1_un || !desc1 || !prev_matched || !matches12)) return ORBX_ERR_BAD_ARG;
+  *nmatches = 0;
+  if (rounds) *rounds = 0;
+  if (n1 == 0) return ORBX_OK;
+  if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  auto& last_hip_error = ex->last_hip_error;
+  hipStream_t s = ex->stream;
+  int n2 = 0;
+  HIP_TRY(hipMemcpyAsync(&n2, ex->d_n + frame2, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  const size_t a1 = (size_t)n1, a2 = (size_t)std::max(n2, 1);
+  Carver c;
+  const size_t oK1 = c.add(a1 * 28), oD1 = c.add(a1 * 32), oPm = c.add(a1 * 8),
+               oWork = c.add(orbx::init_work_ints(n1, (int)a2) * 4), oM12 = c.add(a1 * 4), oSum = c.add(8);
+  uint8_t* d = nullptr;
+  hipError_t e = hipMallocAsync((void**)&d, c.total, s);
+  if (e != hipSuccess) { last_hip_error = e; return ORBX_ERR_HIP; }
+  if (e == hipSuccess) e = hipMemcpyAsync(d + oK1, kps1_un, a1 * 28, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(d + oD1, desc1, a1 * 32, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(d + oPm, prev_matched, a1 * 8, hipMemcpyHostToDevice, s);
+  int sum[2] = {0, 0};
+  if (e == hipSuccess) {
+    const size_t base = (size_t)frame2 * ex->hp.kp_cap;
+    orbx::launch_search_for_initialization(
+        (const float*)(d + oK1), d + oD1, n1, (float*)(d + oPm), ex->d_kpsUn + base * 7, ex->d_desc + base * 32, n2,
+        ex->d_cellStart + (size_t)frame2 * (ORBX_GRID_CELLS + 1), ex->d_cellEntries + base, ex->gridBounds,
+        (float)window_size, nnratio, check_orientation != 0, (int*)(d + oWork), (int*)(d + oM12),
+        (int*)(d + oSum), s);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(matches12, d + oM12, a1 * 4, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(prev_matched, d + oPm, a1 * 8, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(sum, d + oSum, 8, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFreeAsync(d, s);
+  if (e != hipSuccess) { last_hip_error = e; return ORBX_ERR_HIP; }
+  *nmatches = sum[0];
+  if (rounds) *rounds = sum[1];
   return ORBX_OK;
 }
 

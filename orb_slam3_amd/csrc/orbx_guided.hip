@@ -1,0 +1,440 @@
+// Guided matchers on a device-resident frame (undistorted keypoints, descriptors and the
+// 64 x 48 frame grid of orbx_grid.hip):
+//   k_search_by_projection_last   ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono)
+//                                 core/lib/ORB/matcher.cc:1591-1808 (monocular / rectified case)
+//   k_search_for_initialization   ORBmatcher::SearchForInitialization   matcher.cc:629-733
+//   three_maxima                  ORBmatcher::ComputeThreeMaxima        matcher.cc:1925-1957
+//
+// Both reference loops are greedy over the query index: what query i may take depends on what
+// the queries before it took (a keypoint that received a map point with observations is closed
+// to later queries; a keypoint already matched at distance d only accepts a closer match).
+// Here every query decides on its own from the claims that LOWER-indexed queries made in the
+// previous round, and rounds repeat until no decision changes.  Query 0 depends on nobody and
+// is right after round 1; query i is right once everything below it is; so the fixed point is
+// unique, equals the sequential result, and is reached after (longest dependency chain + 1)
+// rounds - a handful in practice, never more than the number of queries + 1.
+//
+// One workgroup per call: the work is a few thousand window walks of a few dozen 256-bit
+// distances each, the rounds need workgroup-wide barriers, and the caller (Tracking) has one
+// frame at a time.  Latency-bound by design.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/orbx.h"
+#include "orbx_plan.h"
+
+#define GRID_COLS 64   /* FRAME_GRID_COLS, core/include/Frame.h:47 */
+#define GRID_ROWS 48   /* FRAME_GRID_ROWS, core/include/Frame.h:46 */
+#define HISTO_LENGTH 30   /* ORBmatcher::HISTO_LENGTH, matcher.cc:36 */
+#define TH_HIGH 100       /* matcher.cc:34 */
+#define TH_LOW 50         /* matcher.cc:35 */
+#define GUIDED_THREADS 256
+
+namespace orbx {
+
+namespace {
+
+struct GKP { float x, y, size, angle, response; int octave, class_id; };
+
+struct GridView {
+  const GKP* U;        // undistorted keypoints of the frame
+  const int* cs;       // cell starts, 64*48 + 1
+  const int* ent;      // cell entries
+  float minX, maxX, minY, maxY, invW, invH;
+};
+
+// Frame::GetFeaturesInArea (core/src/Frame.cc:682-749): calls visit(i2) for every keypoint of
+// the window, in the reference's order (cell column, cell row, order inside the cell).
+template <class F>
+__device__ __forceinline__ void for_each_in_area(const GridView& g, float x, float y, float r, int minLevel,
+                                                 int maxLevel, F visit) {
+  const int nMinCellX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, g.minX), r), g.invW)));
+  if (nMinCellX >= GRID_COLS) return;
+  const int nMaxCellX = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, g.minX), r), g.invW)));
+  if (nMaxCellX < 0) return;
+  const int nMinCellY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, g.minY), r), g.invH)));
+  if (nMinCellY >= GRID_ROWS) return;
+  const int nMaxCellY = min(GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, g.minY), r), g.invH)));
+  if (nMaxCellY < 0) return;
+  const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+  for (int ix = nMinCellX; ix <= nMaxCellX; ++ix)
+    for (int iy = nMinCellY; iy <= nMaxCellY; ++iy) {
+      const int c = ix * GRID_ROWS + iy;
+      const int e1 = g.cs[c + 1];
+      for (int e = g.cs[c]; e < e1; ++e) {
+        const int i2 = g.ent[e];
+        const GKP kp = g.U[i2];
+        if (bCheckLevels) {
+          if (kp.octave < minLevel) continue;
+          if (maxLevel >= 0 && kp.octave > maxLevel) continue;
+        }
+        const float distx = __fsub_rn(kp.x, x), disty = __fsub_rn(kp.y, y);
+        if (fabsf(distx) < r && fabsf(disty) < r) visit(i2);
+      }
+    }
+}
+
+// Words that other threads of the workgroup update with atomics (which execute in L2) are
+// read with agent-scope atomic loads, so that a read never depends on how the CU's vector
+// cache treats a line it holds while an atomic goes past it.
+__device__ __forceinline__ int coherent_load(const int* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ORBmatcher::DescriptorDistance (matcher.cc:1961-1975) of a descriptor held in registers
+__device__ __forceinline__ int hamming_reg(const uint32_t (&a)[8], const uint32_t* __restrict__ b) {
+  int d = 0;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) d += __builtin_popcount(a[w] ^ b[w]);
+  return d;
+}
+
+// rotation histogram bin as written at matcher.cc:694-700 / :1691-1699: the product with
+// 1/HISTO_LENGTH (not a division by the bin width), round() half away from zero
+__device__ __forceinline__ int rotation_bin(float angle1, float angle2) {
+  const float factor = 1.0f / HISTO_LENGTH;
+  float rot = __fsub_rn(angle1, angle2);
+  if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+  int bin = (int)roundf(__fmul_rn(rot, factor));
+  if (bin == HISTO_LENGTH) bin = 0;
+  return bin;
+}
+
+// ORBmatcher::ComputeThreeMaxima, matcher.cc:1925-1957
+__device__ void three_maxima(const int* histo, int L, int* ind) {
+  int max1 = 0, max2 = 0, max3 = 0;
+  int ind1 = -1, ind2 = -1, ind3 = -1;
+  for (int i = 0; i < L; ++i) {
+    const int s = histo[i];
+    if (s > max1) {
+      max3 = max2; max2 = max1; max1 = s;
+      ind3 = ind2; ind2 = ind1; ind1 = i;
+    } else if (s > max2) {
+      max3 = max2; max2 = s;
+      ind3 = ind2; ind2 = i;
+    } else if (s > max3) {
+      max3 = s;
+      ind3 = i;
+    }
+  }
+  if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+  else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
+  ind[0] = ind1; ind[1] = ind2; ind[2] = ind3;
+}
+
+}  // namespace
+
+struct ProjectionArgs {
+  // last frame, one entry per keypoint of the last frame (matcher.cc:1607-1613, 1632-1635, 1655)
+  const uint8_t* lastValid;
+  const float* uv;
+  const float* invz;
+  const int* lastOctave;
+  const float* lastAngle;
+  const uint32_t* lastDesc;
+  const uint8_t* lastObs;
+  int nLast;
+  // current frame
+  GridView grid;
+  const uint32_t* desc;
+  const float* uRight;     // may be null: monocular
+  const uint8_t* state;    // may be null: every keypoint free
+  int n;
+  float scale[ORBX_MAX_LEVELS];
+  float th, mbf;
+  int forward, backward, checkOrientation;
+  // work arrays: two generations of choices (nLast) and of closing times (n)
+  int* choice[2];
+  int* closedAt[2];
+  // results
+  int* assigned;           // n
+  int* summary;            // [0] nmatches, [1] rounds
+};
+
+// choice of last-frame keypoint i given the closing times of the previous round
+// (matcher.cc:1607-1690): the keypoint it matches, or -1
+__device__ int projection_choice(const ProjectionArgs& a, int i, const int* closedAt) {
+  if (!a.lastValid[i]) return -1;
+  const float invzc = a.invz[i];
+  if (invzc < 0) return -1;
+  const float u = a.uv[2 * i], v = a.uv[2 * i + 1];
+  if (u < a.grid.minX || u > a.grid.maxX) return -1;
+  if (v < a.grid.minY || v > a.grid.maxY) return -1;
+  const int nLastOctave = a.lastOctave[i];
+  const float radius = __fmul_rn(a.th, a.scale[nLastOctave]);
+  int minLevel, maxLevel;
+  if (a.forward) { minLevel = nLastOctave; maxLevel = -1; }
+  else if (a.backward) { minLevel = 0; maxLevel = nLastOctave; }
+  else { minLevel = nLastOctave - 1; maxLevel = nLastOctave + 1; }
+  uint32_t dMP[8];
+#pragma unroll
+  for (int w = 0; w < 8; ++w) dMP[w] = a.lastDesc[(size_t)i * 8 + w];
+  const float ur = __fsub_rn(u, __fmul_rn(a.mbf, invzc));
+  int bestDist = 256, bestIdx2 = -1;
+  for_each_in_area(a.grid, u, v, radius, minLevel, maxLevel, [&](int i2) {
+    // closed: the keypoint holds a map point with observations, from the start (-1) or
+    // since an earlier query put one there (matcher.cc:1663-1666)
+    if (coherent_load(&closedAt[i2]) < i) return;
+    if (a.uRight) {
+      const float r2 = a.uRight[i2];
+      if (r2 > 0) {
+        const float er = fabsf(__fsub_rn(ur, r2));
+        if (er > radius) return;
+      }
+    }
+    const int dist = hamming_reg(dMP, a.desc + (size_t)i2 * 8);
+    if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+  });
+  return bestDist <= TH_HIGH ? bestIdx2 : -1;
+}
+
+__global__ __launch_bounds__(GUIDED_THREADS) void k_search_by_projection_last(ProjectionArgs a) {
+  __shared__ int hist[HISTO_LENGTH];
+  __shared__ int keep[3];
+  __shared__ int nmS;
+  const int tid = threadIdx.x;
+  const int OPEN = 0x7fffffff;
+  for (int i = tid; i < a.nLast; i += GUIDED_THREADS) a.choice[0][i] = -1;
+  for (int i2 = tid; i2 < a.n; i2 += GUIDED_THREADS)
+    a.closedAt[0][i2] = (a.state && a.state[i2] == 1) ? -1 : OPEN;
+  if (tid < HISTO_LENGTH) hist[tid] = 0;
+  if (tid == 0) nmS = 0;
+  __syncthreads();
+  int cur = 0, rounds = 0;
+  for (;;) {
+    const int* cPrev = a.choice[cur];
+    int* cNew = a.choice[cur ^ 1];
+    const int* bPrev = a.closedAt[cur];
+    int* bNew = a.closedAt[cur ^ 1];
+    int changed = 0;
+    for (int i = tid; i < a.nLast; i += GUIDED_THREADS) {
+      const int c = projection_choice(a, i, bPrev);
+      cNew[i] = c;
+      changed |= (c != cPrev[i]) ? 1 : 0;
+    }
+    for (int i2 = tid; i2 < a.n; i2 += GUIDED_THREADS)
+      bNew[i2] = (a.state && a.state[i2] == 1) ? -1 : OPEN;
+    __syncthreads();
+    // a keypoint closes at the first query that puts a map point with observations there
+    for (int i = tid; i < a.nLast; i += GUIDED_THREADS) {
+      const int c = cNew[i];
+      if (c >= 0 && a.lastObs[i]) atomicMin(&bNew[c], i);
+    }
+    ++rounds;
+    cur ^= 1;
+    const int any = __syncthreads_or(changed);
+    if (!any || rounds > a.nLast + 1) break;
+  }
+  // matcher.cc:1682-1700: the last query that took a keypoint keeps it; every take counts
+  const int* choice = a.choice[cur];
+  for (int i2 = tid; i2 < a.n; i2 += GUIDED_THREADS) a.assigned[i2] = -1;
+  __syncthreads();
+  for (int i = tid; i < a.nLast; i += GUIDED_THREADS) {
+    const int c = choice[i];
+    if (c >= 0) {
+      atomicMax(&a.assigned[c], i);
+      atomicAdd(&nmS, 1);
+      if (a.checkOrientation) {
+        const int bin = rotation_bin(a.lastAngle[i], a.grid.U[c].angle);
+        if (bin >= 0 && bin < HISTO_LENGTH) atomicAdd(&hist[bin], 1);
+      }
+    }
+  }
+  __syncthreads();
+  if (a.checkOrientation) {
+    // matcher.cc:1788-1805: keypoints of every bin but the three largest lose their map point
+    if (tid == 0) three_maxima(hist, HISTO_LENGTH, keep);
+    __syncthreads();
+    for (int i = tid; i < a.nLast; i += GUIDED_THREADS) {
+      const int c = choice[i];
+      if (c >= 0) {
+        const int bin = rotation_bin(a.lastAngle[i], a.grid.U[c].angle);
+        if (bin >= 0 && bin < HISTO_LENGTH && bin != keep[0] && bin != keep[1] && bin != keep[2]) {
+          a.assigned[c] = -2;
+          atomicSub(&nmS, 1);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) { a.summary[0] = nmS; a.summary[1] = rounds; }
+}
+
+struct InitArgs {
+  // frame 1 (reference frame of the initialisation)
+  const GKP* K1;
+  const uint32_t* desc1;
+  int n1;
+  float* prevMatched;      // n1 (x, y) pairs, in / out (matcher.cc:728-730)
+  // frame 2
+  GridView grid;
+  const uint32_t* desc2;
+  int n2;
+  float window, nnratio;
+  int checkOrientation;
+  // work arrays: two generations of claims (keypoint, distance) per query of frame 1;
+  // claimants of a keypoint as a linked list (head per keypoint, next per query)
+  int* claim[2];
+  int* claimDist[2];
+  int* head;               // n2; reused as owner at the end
+  int* next;               // n1
+  // results
+  int* matches12;          // n1
+  int* summary;            // [0] nmatches, [1] rounds
+};
+
+// claim of query i1 given the claims of the previous round (matcher.cc:638-704)
+__device__ void init_choice(const InitArgs& a, int i1, const int* claimDistPrev, int* kpOut, int* distOut) {
+  *kpOut = -1;
+  *distOut = 0x7fffffff;
+  const GKP kp1 = a.K1[i1];
+  const int level1 = kp1.octave;
+  if (level1 > 0) return;
+  uint32_t d1[8];
+#pragma unroll
+  for (int w = 0; w < 8; ++w) d1[w] = a.desc1[(size_t)i1 * 8 + w];
+  int bestDist = 0x7fffffff, bestDist2 = 0x7fffffff, bestIdx2 = -1;
+  for_each_in_area(a.grid, a.prevMatched[2 * i1], a.prevMatched[2 * i1 + 1], a.window, level1, level1, [&](int i2) {
+    const int dist = hamming_reg(d1, a.desc2 + (size_t)i2 * 8);
+    // vMatchedDistance[i2] as query i1 meets it: the smallest distance accepted by an earlier query
+    int seen = 0x7fffffff;
+    for (int j = coherent_load(&a.head[i2]); j >= 0; j = a.next[j])
+      if (j < i1) seen = min(seen, claimDistPrev[j]);
+    if (seen <= dist) return;
+    if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+    else if (dist < bestDist2) { bestDist2 = dist; }
+  });
+  if (bestDist <= TH_LOW && (float)bestDist < __fmul_rn((float)bestDist2, a.nnratio)) {
+    *kpOut = bestIdx2;
+    *distOut = bestDist;
+  }
+}
+
+__global__ __launch_bounds__(GUIDED_THREADS) void k_search_for_initialization(InitArgs a) {
+  __shared__ int hist[HISTO_LENGTH];
+  __shared__ int keep[3];
+  __shared__ int nmS;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < a.n1; i += GUIDED_THREADS) { a.claim[0][i] = -1; a.claimDist[0][i] = 0x7fffffff; }
+  if (tid < HISTO_LENGTH) hist[tid] = 0;
+  if (tid == 0) nmS = 0;
+  __syncthreads();
+  int cur = 0, rounds = 0;
+  for (;;) {
+    const int* cPrev = a.claim[cur];
+    const int* dPrev = a.claimDist[cur];
+    int* cNew = a.claim[cur ^ 1];
+    int* dNew = a.claimDist[cur ^ 1];
+    for (int i2 = tid; i2 < a.n2; i2 += GUIDED_THREADS) a.head[i2] = -1;
+    __syncthreads();
+    for (int i = tid; i < a.n1; i += GUIDED_THREADS) {
+      const int c = cPrev[i];
+      if (c >= 0) a.next[i] = atomicExch(&a.head[c], i);
+    }
+    __syncthreads();
+    int changed = 0;
+    for (int i = tid; i < a.n1; i += GUIDED_THREADS) {
+      int c, d;
+      init_choice(a, i, dPrev, &c, &d);
+      cNew[i] = c;
+      dNew[i] = d;
+      changed |= (c != cPrev[i]) ? 1 : 0;
+    }
+    ++rounds;
+    cur ^= 1;
+    const int any = __syncthreads_or(changed);
+    if (!any || rounds > a.n1 + 1) break;
+  }
+  // matcher.cc:690-702: the last query that claimed a keypoint owns it (earlier owners were
+  // reset to -1); every accepted claim entered the rotation histogram
+  const int* claim = a.claim[cur];
+  int* owner = a.head;
+  for (int i2 = tid; i2 < a.n2; i2 += GUIDED_THREADS) owner[i2] = -1;
+  __syncthreads();
+  for (int i = tid; i < a.n1; i += GUIDED_THREADS) {
+    const int c = claim[i];
+    if (c >= 0) {
+      atomicMax(&owner[c], i);
+      if (a.checkOrientation) {
+        const int bin = rotation_bin(a.K1[i].angle, a.grid.U[c].angle);
+        if (bin >= 0 && bin < HISTO_LENGTH) atomicAdd(&hist[bin], 1);
+      }
+    }
+  }
+  __syncthreads();
+  if (a.checkOrientation && tid == 0) three_maxima(hist, HISTO_LENGTH, keep);
+  __syncthreads();
+  for (int i = tid; i < a.n1; i += GUIDED_THREADS) {
+    const int c = claim[i];
+    int m = (c >= 0 && coherent_load(&owner[c]) == i) ? c : -1;
+    if (m >= 0 && a.checkOrientation) {
+      // matcher.cc:708-725
+      const int bin = rotation_bin(a.K1[i].angle, a.grid.U[c].angle);
+      if (bin >= 0 && bin < HISTO_LENGTH && bin != keep[0] && bin != keep[1] && bin != keep[2]) m = -1;
+    }
+    a.matches12[i] = m;
+    if (m >= 0) {
+      atomicAdd(&nmS, 1);
+      a.prevMatched[2 * i] = a.grid.U[m].x;       // matcher.cc:728-730
+      a.prevMatched[2 * i + 1] = a.grid.U[m].y;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) { a.summary[0] = nmS; a.summary[1] = rounds; }
+}
+
+static GridView make_grid(const float* d_kpsUn, const int* d_cellStart, const int* d_entries, const float* bounds) {
+  GridView g;
+  g.U = (const GKP*)d_kpsUn;
+  g.cs = d_cellStart;
+  g.ent = d_entries;
+  g.minX = bounds[0]; g.maxX = bounds[1]; g.minY = bounds[2]; g.maxY = bounds[3];
+  g.invW = (float)GRID_COLS / (bounds[1] - bounds[0]);   // Frame.cc:193-196
+  g.invH = (float)GRID_ROWS / (bounds[3] - bounds[2]);
+  return g;
+}
+
+// work memory either launcher needs beyond its inputs and outputs, in ints
+size_t projection_work_ints(int nLast, int n) { return 2 * (size_t)nLast + 2 * (size_t)n; }
+size_t init_work_ints(int n1, int n2) { return 5 * (size_t)n1 + (size_t)n2; }
+
+void launch_search_by_projection_last(const uint8_t* d_lastValid, const float* d_uv, const float* d_invz,
+                                      const int* d_lastOctave, const float* d_lastAngle, const uint8_t* d_lastDesc,
+                                      const uint8_t* d_lastObs, int nLast, const float* d_kpsUn,
+                                      const uint8_t* d_desc, const float* d_uRight, const uint8_t* d_state, int n,
+                                      const int* d_cellStart, const int* d_entries, const float* bounds,
+                                      const float* scaleFactors, int nlevels, float th, int forward, int backward,
+                                      float mbf, int checkOrientation, int* d_work, int* d_assigned, int* d_summary,
+                                      hipStream_t s) {
+  ProjectionArgs a;
+  a.lastValid = d_lastValid; a.uv = d_uv; a.invz = d_invz; a.lastOctave = d_lastOctave;
+  a.lastAngle = d_lastAngle; a.lastDesc = (const uint32_t*)d_lastDesc; a.lastObs = d_lastObs; a.nLast = nLast;
+  a.grid = make_grid(d_kpsUn, d_cellStart, d_entries, bounds);
+  a.desc = (const uint32_t*)d_desc; a.uRight = d_uRight; a.state = d_state; a.n = n;
+  for (int l = 0; l < ORBX_MAX_LEVELS; ++l) a.scale[l] = l < nlevels ? scaleFactors[l] : 1.0f;
+  a.th = th; a.mbf = mbf; a.forward = forward; a.backward = backward; a.checkOrientation = checkOrientation;
+  a.choice[0] = d_work; a.choice[1] = d_work + nLast;
+  a.closedAt[0] = d_work + 2 * (size_t)nLast; a.closedAt[1] = a.closedAt[0] + n;
+  a.assigned = d_assigned; a.summary = d_summary;
+  hipLaunchKernelGGL(k_search_by_projection_last, dim3(1), dim3(GUIDED_THREADS), 0, s, a);
+}
+
+void launch_search_for_initialization(const float* d_kps1Un, const uint8_t* d_desc1, int n1, float* d_prevMatched,
+                                      const float* d_kps2Un, const uint8_t* d_desc2, int n2,
+                                      const int* d_cellStart2, const int* d_entries2, const float* bounds2,
+                                      float window, float nnratio, int checkOrientation, int* d_work,
+                                      int* d_matches12, int* d_summary, hipStream_t s) {
+  InitArgs a;
+  a.K1 = (const GKP*)d_kps1Un; a.desc1 = (const uint32_t*)d_desc1; a.n1 = n1; a.prevMatched = d_prevMatched;
+  a.grid = make_grid(d_kps2Un, d_cellStart2, d_entries2, bounds2);
+  a.desc2 = (const uint32_t*)d_desc2; a.n2 = n2;
+  a.window = window; a.nnratio = nnratio; a.checkOrientation = checkOrientation;
+  a.claim[0] = d_work; a.claim[1] = d_work + n1;
+  a.claimDist[0] = d_work + 2 * (size_t)n1; a.claimDist[1] = d_work + 3 * (size_t)n1;
+  a.next = d_work + 4 * (size_t)n1;
+  a.head = d_work + 5 * (size_t)n1;
+  a.matches12 = d_matches12; a.summary = d_summary;
+  hipLaunchKernelGGL(k_search_for_initialization, dim3(1), dim3(GUIDED_THREADS), 0, s, a);
+}
+
+}  // namespace orbx

@@ -1,0 +1,60 @@
+"""Host mirror of the guided matchers that walk the frame grid:
+ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) (core/lib/ORB/matcher.cc:
+1591-1808) and ORBmatcher::SearchForInitialization (:629-733).  The current frame is a frame of
+an ORBextractor's last batch for which grid.frame_grid_batch() has run; all device work runs
+in liborbx_hip.so."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import KEYPOINT_DTYPE, check, lib, ptr
+
+_f32p = C.POINTER(C.c_float)
+_i32p = C.POINTER(C.c_int32)
+
+
+def search_by_projection_last(ex, frame, last_valid, uv, invz, last_octave, last_angle, last_desc, last_obs,
+                              u_right=None, state=None, th=15.0, forward=False, backward=False, mbf=0.0,
+                              check_orientation=True):
+    """-> (nmatches, assigned[n], rounds).  assigned[i2] = index of the last-frame keypoint whose
+    map point current keypoint i2 received, -1 untouched, -2 cleared by the rotation check."""
+    lv = np.ascontiguousarray(last_valid, np.uint8)
+    n_last = len(lv)
+    uvf = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
+    iz = np.ascontiguousarray(invz, np.float32)
+    lo = np.ascontiguousarray(last_octave, np.int32)
+    la = np.ascontiguousarray(last_angle, np.float32)
+    ld = np.ascontiguousarray(last_desc, np.uint8).reshape(-1, 32)
+    lobs = np.ascontiguousarray(last_obs, np.uint8)
+    assert len(uvf) == len(iz) == len(lo) == len(la) == len(ld) == len(lobs) == n_last
+    cap = ex.max_keypoints()
+    ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+    st = None if state is None else np.ascontiguousarray(state, np.uint8)
+    out = np.zeros(cap, np.int32)
+    n, nm, rounds = C.c_int32(), C.c_int32(), C.c_int32()
+    check(lib().orbx_search_by_projection_last(
+        ex._h, int(frame), n_last, ptr(lv), uvf.ctypes.data_as(_f32p), iz.ctypes.data_as(_f32p),
+        lo.ctypes.data_as(_i32p), la.ctypes.data_as(_f32p), ptr(ld), ptr(lobs), ptr(ur), ptr(st), float(th),
+        int(bool(forward)), int(bool(backward)), float(mbf), int(bool(check_orientation)), ptr(out), cap,
+        C.byref(n), C.byref(nm), C.byref(rounds)), "orbx_search_by_projection_last")
+    if ur is not None:
+        assert len(ur) >= n.value
+    if st is not None:
+        assert len(st) >= n.value
+    return nm.value, out[:n.value].copy(), rounds.value
+
+
+def search_for_initialization(ex2, frame2, kps1_un, desc1, prev_matched, window_size=100, nnratio=0.9,
+                              check_orientation=True):
+    """-> (nmatches, matches12[n1], prev_matched[n1, 2] updated, rounds)."""
+    k1 = np.ascontiguousarray(kps1_un, KEYPOINT_DTYPE)
+    d1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32)
+    pm = np.ascontiguousarray(prev_matched, np.float32).reshape(-1, 2).copy()
+    assert len(k1) == len(d1) == len(pm)
+    m12 = np.full(max(len(k1), 1), -1, np.int32)
+    nm, rounds = C.c_int32(), C.c_int32()
+    check(lib().orbx_search_for_initialization(
+        ex2._h, int(frame2), len(k1), ptr(k1), ptr(d1), pm.ctypes.data_as(_f32p), int(window_size),
+        float(nnratio), int(bool(check_orientation)), ptr(m12), C.byref(nm), C.byref(rounds)),
+        "orbx_search_for_initialization")
+    return nm.value, m12[:len(k1)].copy(), pm, rounds.value

@@ -311,6 +311,11 @@ static inline float max(float a, float b) { return fmaxf(a, b); }
 static inline double min(double a, double b) { return fmin(a, b); }
 static inline double max(double a, double b) { return fmax(a, b); }
 
+#define __HIP_MEMORY_SCOPE_WORKGROUP 3
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __hip_atomic_load(p, order, scope) __atomic_load_n((p), (order))
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), (order))
+
 // ---- atomics (relaxed, like the device ones) ------------------------------------------------
 template <class T> static inline T atomicAdd(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 template <class T> static inline T atomicSub(T* p, T v) { return __atomic_fetch_sub(p, v, __ATOMIC_RELAXED); }
