@@ -297,6 +297,42 @@ int orbx_search_for_initialization(orbx_extractor* f2, int frame2, int n1, const
                                    float nnratio, int check_orientation, int32_t* matches12, int* nmatches,
                                    int* rounds);
 
+/* ---- bag of words ------------------------------------------------------------ */
+/* The reference's ORBVocabulary (core/lib/ORB/vocabulary.h:31-62) in device
+ * memory.  Supported: TF_IDF (0) or TF (1) weighting with L1 scoring (0), the
+ * stock configuration; other combinations return ORBX_ERR_UNSUPPORTED. */
+typedef struct orbx_vocabulary orbx_vocabulary;
+/* ORBVocabulary::loadFromText, core/lib/ORB/vocabulary.cc:96-160: first line
+ * "k L scoring weighting", then one node per line "parent isLeaf d0 .. d31
+ * weight"; nodes and words are numbered in file order.  (The reference's binary
+ * loader, :180-227, reads no node - the node vector is resized to 1 before a
+ * loop bounded by its size - so the text format is the one with defined
+ * behaviour.)  A line without a node, such as the one a trailing newline
+ * leaves, ends the file; the reference turns it into a node with
+ * uninitialised contents. */
+int orbx_vocabulary_load_text(const char* path, int device_id, orbx_vocabulary** out);
+/* The same from arrays: nodes 1..n_nodes in file order (node 0 is the root). */
+int orbx_vocabulary_create(int k, int L, int scoring, int weighting, int n_nodes, const int32_t* parent,
+                           const uint8_t* is_leaf, const uint8_t* descriptors, const double* weights,
+                           int device_id, orbx_vocabulary** out);
+void orbx_vocabulary_destroy(orbx_vocabulary* voc);
+/* n_nodes includes the root. */
+int orbx_vocabulary_info(const orbx_vocabulary* voc, int* k, int* L, int* n_nodes, int* n_words);
+/* Frame::ComputeBoW, core/src/Frame.cc:764-769 (and KeyFrame::ComputeBoW,
+ * core/src/KeyFrame.cc:117-122): vocabulary.transform(descriptors, mBowVec,
+ * mFeatVec, levelsup = 4) for frames [0, n_frames) of the last batched call on
+ * ex, on the descriptors where the extraction left them.  Asynchronous on the
+ * handle's stream. */
+int orbx_bow_transform_batch_device(orbx_extractor* ex, const orbx_vocabulary* voc, int n_frames,
+                                    int levelsup);
+/* Copy frame f to the host (waits).  mBowVec as parallel arrays in ascending
+ * word id: word_ids / word_values (doubles, L1-normalised), *n_words entries.
+ * mFeatVec as a CSR in ascending node id: node_ids (*n_nodes entries),
+ * node_start (*n_nodes + 1), features (keypoint indices, ascending inside a
+ * node).  Every array holds cap entries (node_start cap + 1); any may be NULL. */
+int orbx_bow_download(orbx_extractor* ex, int frame, uint32_t* word_ids, double* word_values, int* n_words,
+                      uint32_t* node_ids, int32_t* node_start, uint32_t* features, int* n_nodes, int cap);
+
 /* ---- synthetic input ------------------------------------------------------- */
 /* Deterministic textured test frame (PCG32-seeded rectangles + noise + 3x3
  * box blur), written to dst (height rows of stride bytes).  Host only. */

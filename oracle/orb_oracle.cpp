@@ -31,7 +31,10 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <cstdio>
 #include <list>
+#include <map>
+#include <string>
 #include <utility>
 #include <vector>
 
@@ -1170,6 +1173,160 @@ int orc_search_by_projection_last(const uint8_t* lastValid, const float* uv, con
     }
   }
   return nmatches;
+}
+
+}  // extern "C"
+
+// ---- bag of words (Frame::ComputeBoW, core/src/Frame.cc:764-769) -----------------------------
+// The vocabulary class of the reference (core/lib/ORB/vocabulary.h:31-62) derives from DBoW2's
+// TemplatedVocabulary<FORB::TDescriptor, FORB>.  DBoW2 is a git submodule (deps/DBoW2) whose
+// directory is empty in the reference tree, so its version is not pinned there; what follows
+// restates the published DBoW2 algorithm (TemplatedVocabulary::transform for one feature and
+// for a feature vector, BowVector::addWeight / normalize, FeatureVector::addFeature,
+// FORB::distance) - "parity unpinned" like the OpenCV primitives.  The file format is the
+// reference's own: ORBVocabulary::loadFromText, core/lib/ORB/vocabulary.cc:96-160.  (Its
+// binary loader, :180-227, sizes the node vector to 1 before a loop bounded by that size and
+// reads no node, so the text format is the only one with defined behaviour.)
+namespace {
+struct VocNode {
+  int parent = 0;
+  std::vector<int> children;
+  uint8_t desc[32] = {0};
+  double weight = 0;
+  unsigned word_id = 0;
+};
+struct Vocabulary {
+  int k = 0, L = 0, scoring = 0, weighting = 0;
+  std::vector<VocNode> nodes;   // nodes[0] = root
+  int nWords = 0;
+  // appends node nid = nodes.size() exactly as vocabulary.cc:130-156 does
+  bool add(int pid, int isLeaf, const uint8_t* d, double w) {
+    const int nid = (int)nodes.size();
+    if (pid < 0 || pid >= nid) return false;   // the reference indexes m_nodes[pid] unchecked
+    nodes.emplace_back();
+    nodes[nid].parent = pid;
+    nodes[pid].children.push_back(nid);
+    std::memcpy(nodes[nid].desc, d, 32);
+    nodes[nid].weight = w;
+    if (isLeaf > 0) nodes[nid].word_id = (unsigned)nWords++;
+    return true;
+  }
+};
+}  // namespace
+
+extern "C" {
+
+// scoring: L1_NORM = 0; weighting: TF_IDF = 0, TF = 1, IDF = 2, BINARY = 3 (DBoW2 enums).
+// Nodes 1..nNodes in file order: parent id, leaf flag, 32 descriptor bytes, weight.
+void* orc_voc_create(int k, int L, int scoring, int weighting, int nNodes, const int* parent,
+                     const uint8_t* isLeaf, const uint8_t* desc, const double* weight) {
+  Vocabulary* v = new Vocabulary();
+  v->k = k; v->L = L; v->scoring = scoring; v->weighting = weighting;
+  v->nodes.resize(1);
+  for (int i = 0; i < nNodes; ++i)
+    if (!v->add(parent[i], isLeaf[i], desc + (size_t)i * 32, weight[i])) { delete v; return nullptr; }
+  return v;
+}
+
+// ORBVocabulary::loadFromText, core/lib/ORB/vocabulary.cc:96-160.  Lines without a parent id
+// (the empty line a trailing newline leaves, which the reference turns into a node with
+// uninitialised contents) are skipped.
+void* orc_voc_load_text(const char* path) {
+  FILE* f = std::fopen(path, "r");
+  if (!f) return nullptr;
+  Vocabulary* v = new Vocabulary();
+  int n1 = 0, n2 = 0;
+  if (std::fscanf(f, "%d %d %d %d", &v->k, &v->L, &n1, &n2) != 4 || v->k < 0 || v->k > 20 || v->L < 1 ||
+      v->L > 10 || n1 < 0 || n1 > 5 || n2 < 0 || n2 > 3) {
+    std::fclose(f); delete v; return nullptr;
+  }
+  v->scoring = n1; v->weighting = n2;
+  v->nodes.resize(1);
+  for (;;) {
+    int pid, leaf;
+    if (std::fscanf(f, "%d %d", &pid, &leaf) != 2) break;
+    uint8_t d[32];
+    bool ok = true;
+    for (int i = 0; i < 32 && ok; ++i) {
+      int b;
+      ok = std::fscanf(f, "%d", &b) == 1;
+      d[i] = (uint8_t)b;
+    }
+    double w = 0;
+    ok = ok && std::fscanf(f, "%lf", &w) == 1;
+    if (!ok || !v->add(pid, leaf, d, w)) { std::fclose(f); delete v; return nullptr; }
+  }
+  std::fclose(f);
+  return v;
+}
+
+void orc_voc_destroy(void* h) { delete (Vocabulary*)h; }
+
+void orc_voc_info(void* h, int* k, int* L, int* nNodes, int* nWords) {
+  Vocabulary* v = (Vocabulary*)h;
+  *k = v->k; *L = v->L; *nNodes = (int)v->nodes.size(); *nWords = v->nWords;
+}
+
+// TemplatedVocabulary::transform(features, BowVector&, FeatureVector&, levelsup) for TF_IDF / TF
+// weighting and L1 scoring (the stock configuration; anything else returns -1).
+//   per feature: descend from the root, at every level the child at the smallest Hamming
+//     distance (first one wins ties); the node met at level L - levelsup is the feature's node
+//     id (0 when L - levelsup <= 0, and - where the original leaves it uninitialised, a leaf
+//     above that level - also 0); the leaf's word id and weight;
+//   BowVector (std::map<WordId, double>): weights with w > 0 are added up per word in feature
+//     order, then divided by the L1 norm summed in ascending word order;
+//   FeatureVector (std::map<NodeId, vector<unsigned>>): feature indices per node id.
+// Outputs: words ascending with their values; node ids ascending with a CSR of feature indices.
+int orc_bow_transform(void* h, const uint8_t* desc, int n, int levelsup, uint32_t* wordIds, double* wordVals,
+                      int* nWordsOut, uint32_t* nodeIds, int* nodeStart, uint32_t* feats, int* nNodesOut) {
+  Vocabulary* v = (Vocabulary*)h;
+  *nWordsOut = 0; *nNodesOut = 0;
+  if (v->scoring != 0 || (v->weighting != 0 && v->weighting != 1)) return -1;
+  if (v->nodes.size() <= 1) return 0;   // empty()
+  std::map<unsigned, double> bow;
+  std::map<unsigned, std::vector<unsigned>> fv;
+  const int nid_level = v->L - levelsup;
+  for (int i = 0; i < n; ++i) {
+    const uint8_t* f = desc + (size_t)i * 32;
+    unsigned nid = 0;
+    int final_id = 0, current_level = 0;
+    do {
+      ++current_level;
+      const std::vector<int>& ch = v->nodes[final_id].children;
+      final_id = ch[0];
+      double best_d = hamming256(f, v->nodes[final_id].desc);
+      for (size_t c = 1; c < ch.size(); ++c) {
+        const double d = hamming256(f, v->nodes[ch[c]].desc);
+        if (d < best_d) { best_d = d; final_id = ch[c]; }
+      }
+      if (current_level == nid_level) nid = (unsigned)final_id;
+    } while (!v->nodes[final_id].children.empty());
+    const unsigned word = v->nodes[final_id].word_id;
+    const double w = v->weighting == 1 ? 1.0 : v->nodes[final_id].weight;   // TF: weight 1
+    if (w > 0) {
+      auto it = bow.lower_bound(word);
+      if (it != bow.end() && !(bow.key_comp()(word, it->first))) it->second += w;
+      else bow.insert(it, std::make_pair(word, w));
+      fv[nid].push_back((unsigned)i);
+    }
+  }
+  double norm = 0.0;
+  for (auto& kv : bow) norm += std::fabs(kv.second);
+  if (norm > 0.0)
+    for (auto& kv : bow) kv.second /= norm;
+  int a = 0;
+  for (auto& kv : bow) { wordIds[a] = kv.first; wordVals[a] = kv.second; ++a; }
+  *nWordsOut = a;
+  int b = 0, run = 0;
+  for (auto& kv : fv) {
+    nodeIds[b] = kv.first;
+    nodeStart[b] = run;
+    for (unsigned idx : kv.second) feats[run++] = idx;
+    ++b;
+  }
+  nodeStart[b] = run;
+  *nNodesOut = b;
+  return 0;
 }
 
 }  // extern "C"

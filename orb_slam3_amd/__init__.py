@@ -6,6 +6,7 @@ Host-side mirror of the reference's interface for this path:
   knn_match2 / stereo_band_match   the matching loops of core/src/Frame.cc:1177, 840-908
   compute_stereo_matches    Frame::ComputeStereoMatches, core/src/Frame.cc:831-996
   grid.*                    UndistortKeyPoints / AssignFeaturesToGrid / GetFeaturesInArea, Frame.cc:432-459, 682-829
+  bow.*                     ORBVocabulary (text format) / Frame::ComputeBoW, vocabulary.cc:96-160, Frame.cc:764-769
   guided.*                  ORBmatcher::SearchByProjection(Frame, LastFrame) / SearchForInitialization, matcher.cc:1591-1808, 629-733
 All compute runs in liborbx_hip.so (hand-written gfx950 kernels behind the C
 ABI of include/orbx.h); this package only marshals arguments.
@@ -18,3 +19,4 @@ from .matcher import (descriptor_distance, knn_match2, ratio_test, stereo_band_m
 from .synth import textured_frame, right_view  # noqa: F401
 from . import grid  # noqa: F401
 from . import guided  # noqa: F401
+from . import bow  # noqa: F401

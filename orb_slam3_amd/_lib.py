@@ -99,6 +99,13 @@ SIGNATURES = {
                                                  _i32p, _i32p, _i32p]),
     "orbx_search_for_initialization": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _f32p, C.c_int, C.c_float,
                                                  C.c_int, _P, _i32p, _i32p]),
+    "orbx_vocabulary_load_text": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(_P)]),
+    "orbx_vocabulary_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _i32p, _P, _P, _P, C.c_int,
+                                         C.POINTER(_P)]),
+    "orbx_vocabulary_destroy": (None, [_P]),
+    "orbx_vocabulary_info": (C.c_int, [_P, _i32p, _i32p, _i32p, _i32p]),
+    "orbx_bow_transform_batch_device": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "orbx_bow_download": (C.c_int, [_P, C.c_int, _P, _P, _i32p, _P, _P, _P, _i32p, C.c_int]),
     "orbx_synth_frame": (C.c_int, [C.c_uint32, C.c_int, C.c_int, C.c_int, _P]),
 }
 

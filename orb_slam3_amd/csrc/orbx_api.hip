@@ -13,6 +13,7 @@
 
 #include "../../include/orbx.h"
 #include "orbx_plan.h"
+#include "orbx_bow.h"
 
 namespace orbx {
 void launch_pyramid(const Plan& hp, const uint8_t* d_img, int istride, size_t iframe, uint8_t* d_pyr,
@@ -158,6 +159,10 @@ struct orbx_extractor {
   int gridFrames = 0;
   float gridBounds[4] = {0, 0, 0, 0};
   hipEvent_t evStereo = nullptr;
+  // bag-of-words results of the last transform call, allocated by the first one
+  orbx::BowBuffers bow = {};
+  void* d_bowBlock = nullptr;
+  int bowFrames = 0;
 
   // pinned host staging
   // pinned host staging for the host-pointer entry points: two input buffers of stageFrames
@@ -228,6 +233,8 @@ void orbx_extractor::freePlan() {
   (void)hipStreamSynchronize(stream);
   for (void* t : d_taps) (void)hipFree(t);
   d_taps.clear();
+  if (d_bowBlock) (void)hipFree(d_bowBlock);
+  d_bowBlock = nullptr; bowFrames = 0; bow = orbx::BowBuffers{};
   void* gbufs[] = {d_kpsUn, d_cellStart, d_cellEntries};
   for (void* b : gbufs) if (b) (void)hipFree(b);
   d_kpsUn = nullptr; d_cellStart = d_cellEntries = nullptr; gridFrames = 0;
@@ -1102,6 +1109,72 @@ int orbx_search_for_initialization(orbx_extractor* f2, int frame2, int n1, const
   if (e != hipSuccess) { last_hip_error = e; return ORBX_ERR_HIP; }
   *nmatches = sum[0];
   if (rounds) *rounds = sum[1];
+  return ORBX_OK;
+}
+
+// ---- bag of words on a device-resident extraction ----------------------------------------------
+int orbx_bow_transform_batch_device(orbx_extractor* ex, const orbx_vocabulary* voc, int n_frames, int levelsup) {
+  if (!ex || !ex->planned || !voc || n_frames <= 0 || levelsup < 0) return ORBX_ERR_BAD_ARG;
+  if (n_frames > ex->lastFrames) return ORBX_ERR_BATCH;
+  if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  const orbx::VocDevice* vd = orbx::voc_device(voc, ex->device);
+  if (!vd) return ORBX_ERR_BAD_ARG;   // vocabulary lives on another device
+  auto& last_hip_error = ex->last_hip_error;
+  const int cap = ex->hp.kp_cap;
+  if (!ex->d_bowBlock) {
+    const size_t B = (size_t)ex->prm.max_batch;
+    int P = 2;
+    while (P < cap) P <<= 1;
+    const bool keysInLds = orbx::bow_keys_lds_bytes(P) <= 60 * 1024;
+    Carver c;
+    const size_t oFW = c.add(B * cap * 4), oFWt = c.add(B * cap * 8), oFN = c.add(B * cap * 4),
+                 oKeys = c.add(keysInLds ? 0 : B * P * 8), oBW = c.add(B * cap * 4), oBV = c.add(B * cap * 8),
+                 oBC = c.add(B * 4), oVN = c.add(B * cap * 4), oVS = c.add(B * ((size_t)cap + 1) * 4),
+                 oVF = c.add(B * cap * 4), oVC = c.add(B * 4);
+    uint8_t* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, c.total));
+    ex->d_bowBlock = d;
+    orbx::BowBuffers& b = ex->bow;
+    b.featWord = (uint32_t*)(d + oFW); b.featWeight = (double*)(d + oFWt); b.featNode = (uint32_t*)(d + oFN);
+    b.keyWs = keysInLds ? nullptr : (uint64_t*)(d + oKeys); b.P = P;
+    b.bowWord = (uint32_t*)(d + oBW); b.bowVal = (double*)(d + oBV); b.bowCount = (int*)(d + oBC);
+    b.fvNode = (uint32_t*)(d + oVN); b.fvStart = (int*)(d + oVS); b.fvFeat = (uint32_t*)(d + oVF);
+    b.fvCount = (int*)(d + oVC);
+  }
+  orbx::launch_bow(*vd, ex->d_desc, ex->d_n, cap, n_frames, levelsup, ex->bow, ex->stream);
+  HIP_TRY(hipGetLastError());
+  ex->bowFrames = n_frames;
+  return ORBX_OK;
+}
+
+int orbx_bow_download(orbx_extractor* ex, int frame, uint32_t* word_ids, double* word_values, int* n_words,
+                      uint32_t* node_ids, int32_t* node_start, uint32_t* features, int* n_nodes, int cap) {
+  if (!ex || !ex->planned || !ex->d_bowBlock || frame < 0 || frame >= ex->bowFrames || cap < 0)
+    return ORBX_ERR_BAD_ARG;
+  if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  auto& last_hip_error = ex->last_hip_error;
+  hipStream_t s = ex->stream;
+  const orbx::BowBuffers& b = ex->bow;
+  int cnt[2] = {0, 0};
+  HIP_TRY(hipMemcpyAsync(&cnt[0], b.bowCount + frame, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(&cnt[1], b.fvCount + frame, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (n_words) *n_words = cnt[0];
+  if (n_nodes) *n_nodes = cnt[1];
+  if (cnt[0] > cap || cnt[1] > cap) return ORBX_ERR_CAPACITY;
+  const size_t fo = (size_t)frame * ex->hp.kp_cap;
+  int m = 0;   // features that entered the vectors = end of the last node's range
+  HIP_TRY(hipMemcpyAsync(&m, b.fvStart + (size_t)frame * (ex->hp.kp_cap + 1) + cnt[1], 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (m > cap) return ORBX_ERR_CAPACITY;
+  if (word_ids && cnt[0]) HIP_TRY(hipMemcpyAsync(word_ids, b.bowWord + fo, (size_t)cnt[0] * 4, hipMemcpyDeviceToHost, s));
+  if (word_values && cnt[0]) HIP_TRY(hipMemcpyAsync(word_values, b.bowVal + fo, (size_t)cnt[0] * 8, hipMemcpyDeviceToHost, s));
+  if (node_ids && cnt[1]) HIP_TRY(hipMemcpyAsync(node_ids, b.fvNode + fo, (size_t)cnt[1] * 4, hipMemcpyDeviceToHost, s));
+  if (node_start)
+    HIP_TRY(hipMemcpyAsync(node_start, b.fvStart + (size_t)frame * (ex->hp.kp_cap + 1), (size_t)(cnt[1] + 1) * 4,
+                           hipMemcpyDeviceToHost, s));
+  if (features && m) HIP_TRY(hipMemcpyAsync(features, b.fvFeat + fo, (size_t)m * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
   return ORBX_OK;
 }
 

@@ -1,0 +1,349 @@
+// Bag-of-words transform of device-resident descriptors:
+//   Frame::ComputeBoW  core/src/Frame.cc:764-769
+//     = ORBVocabulary::transform(descriptors, mBowVec, mFeatVec, 4), the vocabulary class of
+//       core/lib/ORB/vocabulary.h:31-62 on top of DBoW2's TemplatedVocabulary (deps/DBoW2, an
+//       empty submodule directory in the reference tree; its published algorithm is followed).
+//   vocabulary file: ORBVocabulary::loadFromText  core/lib/ORB/vocabulary.cc:96-160
+//
+//   k_bow_descend   per feature, descend the vocabulary tree: at every level the child at the
+//                   smallest Hamming distance, the first one on ties (16 lanes per feature, one
+//                   child per lane, children's descriptors contiguous in memory);
+//   k_bow_assemble  per frame, the two std::map results as sorted arrays: BowVector (word id ->
+//                   weight summed in feature order, L1-normalised in ascending word order) and
+//                   FeatureVector (node id -> feature indices, ascending).
+// Doubles are added in exactly the order the reference adds them, so values are bit-identical.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/orbx.h"
+#include "orbx_bow.h"
+
+namespace orbx {
+
+#define BOW_THREADS 256
+#define BOW_LANES 16   // lanes per feature in k_bow_descend
+
+__global__ __launch_bounds__(BOW_THREADS) void k_bow_descend(VocDevice voc, const uint32_t* __restrict__ desc,
+                                                             const int* __restrict__ nP, int cap,
+                                                             int nidLevel, uint32_t* __restrict__ featWord,
+                                                             double* __restrict__ featWeight,
+                                                             uint32_t* __restrict__ featNode) {
+  const int f = blockIdx.y;
+  const int j = threadIdx.x & (BOW_LANES - 1);
+  const int i = blockIdx.x * (BOW_THREADS / BOW_LANES) + (threadIdx.x / BOW_LANES);
+  if (i >= nP[f]) return;   // uniform over the 16 lanes of a feature
+  const uint32_t* q = desc + ((size_t)f * cap + i) * 8;
+  uint32_t a[8];
+#pragma unroll
+  for (int w = 0; w < 8; ++w) a[w] = q[w];
+  int node = 0, level = 0;
+  uint32_t nid = 0;
+  for (;;) {
+    const int s = voc.childStart[node], e = voc.childStart[node + 1];
+    if (s == e) break;   // Node::isLeaf(): no children
+    ++level;
+    // key = distance << 20 | position among the children: its minimum is the closest child,
+    // the earliest one on ties (strict '<' in the reference's scan)
+    uint32_t best = 0xFFFFFFFFu;
+    for (int c0 = s; c0 < e; c0 += BOW_LANES) {
+      const int c = c0 + j;
+      if (c < e) {
+        const uint32_t* d = voc.childDesc + (size_t)c * 8;
+        uint32_t dist = 0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) dist += (uint32_t)__builtin_popcount(a[w] ^ d[w]);
+        best = min(best, (dist << 20) | (uint32_t)(c - s));
+      }
+    }
+#pragma unroll
+    for (int dd = BOW_LANES / 2; dd >= 1; dd >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, dd, BOW_LANES));
+    node = voc.childId[s + (int)(best & 0xFFFFFu)];
+    if (level == nidLevel) nid = (uint32_t)node;
+  }
+  if (j == 0) {
+    const size_t o = (size_t)f * cap + i;
+    featWord[o] = voc.nodeWord[node];
+    featWeight[o] = voc.weighting == 1 ? 1.0 : voc.nodeWeight[node];   // TF: every word weighs 1
+    featNode[o] = nid;
+  }
+}
+
+// ascending bitonic sort of P (a power of two) 64-bit keys by the whole workgroup
+__device__ void block_sort(uint64_t* keys, int P) {
+  for (int k = 2; k <= P; k <<= 1)
+    for (int jj = k >> 1; jj > 0; jj >>= 1) {
+      for (int t = threadIdx.x; t < P; t += BOW_THREADS) {
+        const int o = t ^ jj;
+        if (o > t) {
+          const uint64_t x = keys[t], y = keys[o];
+          const bool up = (t & k) == 0;
+          if ((x > y) == up) { keys[t] = y; keys[o] = x; }
+        }
+      }
+      __syncthreads();
+    }
+}
+
+// For sorted keys[0..m): run r = maximal range of equal high words.  Writes runStart[r] for
+// every run and runStart[R] = m; returns R.  (Block-wide; scratch = BOW_THREADS ints of LDS.)
+__device__ int block_runs(const uint64_t* keys, int m, int* runStart, int* scratch) {
+  const int tid = threadIdx.x;
+  int base = 0;
+  for (int c0 = 0; c0 < m; c0 += BOW_THREADS) {
+    const int t = c0 + tid;
+    const int head = (t < m && (t == 0 || (uint32_t)(keys[t] >> 32) != (uint32_t)(keys[t - 1] >> 32))) ? 1 : 0;
+    scratch[tid] = head;
+    __syncthreads();
+    // inclusive scan of the 256 flags (Hillis-Steele, 8 steps)
+    for (int d = 1; d < BOW_THREADS; d <<= 1) {
+      const int v = tid >= d ? scratch[tid - d] : 0;
+      __syncthreads();
+      scratch[tid] += v;
+      __syncthreads();
+    }
+    if (head) runStart[base + scratch[tid] - 1] = t;
+    const int total = scratch[BOW_THREADS - 1];
+    __syncthreads();
+    base += total;
+  }
+  if (tid == 0) runStart[base] = m;
+  __syncthreads();
+  return base;
+}
+
+__global__ __launch_bounds__(BOW_THREADS) void k_bow_assemble(const int* __restrict__ nP, int cap, int P,
+                                                              const uint32_t* __restrict__ featWord,
+                                                              const double* __restrict__ featWeight,
+                                                              const uint32_t* __restrict__ featNode,
+                                                              uint64_t* __restrict__ keyWs,
+                                                              uint32_t* __restrict__ bowWord,
+                                                              double* __restrict__ bowVal, int* __restrict__ bowCount,
+                                                              uint32_t* __restrict__ fvNode, int* __restrict__ fvStart,
+                                                              uint32_t* __restrict__ fvFeat, int* __restrict__ fvCount) {
+  extern __shared__ uint64_t sKeys[];
+  __shared__ int scratch[BOW_THREADS];
+  __shared__ int sM;
+  __shared__ double sNorm;
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const int n = nP[f];
+  const size_t fo = (size_t)f * cap;
+  uint64_t* keys = keyWs ? keyWs + (size_t)f * P : sKeys;
+  int* runStart = fvStart + (size_t)f * (cap + 1);   // also used for the word runs, rewritten below
+  // features that take part: weight > 0 ("not stopped")
+  if (tid == 0) sM = 0;
+  __syncthreads();
+  int mine = 0;
+  for (int i = tid; i < n; i += BOW_THREADS) mine += featWeight[fo + i] > 0 ? 1 : 0;
+  atomicAdd(&sM, mine);
+  __syncthreads();
+  const int m = sM;
+
+  // ---- BowVector -------------------------------------------------------------------------
+  for (int t = tid; t < P; t += BOW_THREADS)
+    keys[t] = (t < n && featWeight[fo + t] > 0) ? (((uint64_t)featWord[fo + t] << 32) | (unsigned)t)
+                                                : ~(uint64_t)0;
+  __syncthreads();
+  block_sort(keys, P);
+  const int R = block_runs(keys, m, runStart, scratch);
+  for (int r = tid; r < R; r += BOW_THREADS) {
+    const int s = runStart[r], e = runStart[r + 1];
+    // BowVector::addWeight in feature order: the first occurrence stores w, the others add w
+    const double w = featWeight[fo + (uint32_t)keys[s]];
+    double v = w;
+    for (int c = s + 1; c < e; ++c) v += w;
+    bowWord[fo + r] = (uint32_t)(keys[s] >> 32);
+    bowVal[fo + r] = v;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    // BowVector::normalize(L1): the norm is accumulated in ascending word order
+    double norm = 0.0;
+    for (int r = 0; r < R; ++r) norm += fabs(bowVal[fo + r]);
+    sNorm = norm;
+    bowCount[f] = R;
+  }
+  __syncthreads();
+  const double norm = sNorm;
+  if (norm > 0.0)
+    for (int r = tid; r < R; r += BOW_THREADS) bowVal[fo + r] = bowVal[fo + r] / norm;
+  __syncthreads();
+
+  // ---- FeatureVector ---------------------------------------------------------------------
+  for (int t = tid; t < P; t += BOW_THREADS)
+    keys[t] = (t < n && featWeight[fo + t] > 0) ? (((uint64_t)featNode[fo + t] << 32) | (unsigned)t)
+                                                : ~(uint64_t)0;
+  __syncthreads();
+  block_sort(keys, P);
+  const int Rn = block_runs(keys, m, runStart, scratch);
+  for (int r = tid; r < Rn; r += BOW_THREADS) fvNode[fo + r] = (uint32_t)(keys[runStart[r]] >> 32);
+  for (int t = tid; t < m; t += BOW_THREADS) fvFeat[fo + t] = (uint32_t)keys[t];
+  if (tid == 0) fvCount[f] = Rn;
+}
+
+size_t bow_keys_lds_bytes(int P) { return (size_t)P * 8; }
+
+void launch_bow(const VocDevice& voc, const uint8_t* d_desc, const int* d_n, int cap, int nframes, int levelsup,
+                const BowBuffers& b, hipStream_t s) {
+  const int perBlock = BOW_THREADS / BOW_LANES;
+  hipLaunchKernelGGL(k_bow_descend, dim3((cap + perBlock - 1) / perBlock, nframes), dim3(BOW_THREADS), 0, s, voc,
+                     (const uint32_t*)d_desc, d_n, cap, voc.L - levelsup, b.featWord, b.featWeight, b.featNode);
+  const size_t lds = b.keyWs ? 0 : bow_keys_lds_bytes(b.P);
+  hipLaunchKernelGGL(k_bow_assemble, dim3(nframes), dim3(BOW_THREADS), lds, s, d_n, cap, b.P, b.featWord,
+                     b.featWeight, b.featNode, b.keyWs, b.bowWord, b.bowVal, b.bowCount, b.fvNode, b.fvStart,
+                     b.fvFeat, b.fvCount);
+}
+
+}  // namespace orbx
+
+// ---------------------------------------------------------------------------------------------
+// vocabulary object
+// ---------------------------------------------------------------------------------------------
+struct orbx_vocabulary {
+  int k = 0, L = 0, scoring = 0, weighting = 0;
+  int nNodes = 0;   // including the root
+  int nWords = 0;
+  int device = 0;
+  void* d_block = nullptr;
+  orbx::VocDevice dev;
+};
+
+namespace orbx {
+const VocDevice* voc_device(const orbx_vocabulary* v, int device) {
+  return (v && v->device == device && v->d_block) ? &v->dev : nullptr;
+}
+}  // namespace orbx
+
+namespace {
+
+// Builds the device form from nodes 1..n in file order (parent, leaf flag, descriptor, weight),
+// numbering nodes and words as ORBVocabulary::loadFromText does (vocabulary.cc:130-156).
+int build_vocabulary(int k, int L, int scoring, int weighting, int n, const int32_t* parent, const uint8_t* isLeaf,
+                     const uint8_t* desc, const double* weight, int device_id, orbx_vocabulary** out) {
+  if (!out) return ORBX_ERR_BAD_ARG;
+  *out = nullptr;
+  if (k < 0 || k > 20 || L < 1 || L > 10 || n < 0 || (n > 0 && (!parent || !isLeaf || !desc || !weight)))
+    return ORBX_ERR_BAD_ARG;
+  // TF_IDF (0) or TF (1) weighting with L1 scoring (0): what transform() implements here
+  if (scoring != 0 || (weighting != 0 && weighting != 1)) return ORBX_ERR_UNSUPPORTED;
+  if (n >= (1 << 30)) return ORBX_ERR_UNSUPPORTED;
+  const int N = n + 1;
+  std::vector<int> childCount(N, 0);
+  for (int i = 0; i < n; ++i) {
+    if (parent[i] < 0 || parent[i] > i) return ORBX_ERR_BAD_ARG;   // node i+1 must name an earlier node
+    childCount[parent[i]]++;
+  }
+  for (int c : childCount) if (c >= (1 << 20)) return ORBX_ERR_UNSUPPORTED;   // child position field
+  std::vector<int> childStart(N + 1, 0);
+  for (int i = 0; i < N; ++i) childStart[i + 1] = childStart[i] + childCount[i];
+  std::vector<int> cursor(childStart.begin(), childStart.end() - 1);
+  std::vector<int> childId(std::max(n, 1));
+  std::vector<uint32_t> childDesc((size_t)std::max(n, 1) * 8);
+  std::vector<uint32_t> nodeWord(N, 0);
+  std::vector<double> nodeWeight(N, 0.0);
+  int words = 0;
+  for (int i = 0; i < n; ++i) {
+    const int nid = i + 1, e = cursor[parent[i]]++;   // children in push_back order
+    childId[e] = nid;
+    std::memcpy(&childDesc[(size_t)e * 8], desc + (size_t)i * 32, 32);
+    nodeWeight[nid] = weight[i];
+    if (isLeaf[i] > 0) nodeWord[nid] = (uint32_t)words++;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) return ORBX_ERR_NO_DEVICE;
+  if (hipSetDevice(device_id) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  orbx_vocabulary* v = new (std::nothrow) orbx_vocabulary();
+  if (!v) return ORBX_ERR_BAD_ARG;
+  v->k = k; v->L = L; v->scoring = scoring; v->weighting = weighting;
+  v->nNodes = N; v->nWords = words; v->device = device_id;
+  auto up256 = [](size_t b) { return (b + 255) / 256 * 256; };
+  const size_t oStart = 0, oId = oStart + up256((size_t)(N + 1) * 4), oDesc = oId + up256(childId.size() * 4),
+               oWord = oDesc + up256(childDesc.size() * 4), oWeight = oWord + up256((size_t)N * 4),
+               total = oWeight + up256((size_t)N * 8);
+  uint8_t* d = nullptr;
+  if (hipMalloc((void**)&d, total) != hipSuccess) { delete v; return ORBX_ERR_HIP; }
+  v->d_block = d;
+  hipError_t e = hipMemcpy(d + oStart, childStart.data(), (size_t)(N + 1) * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d + oId, childId.data(), childId.size() * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d + oDesc, childDesc.data(), childDesc.size() * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d + oWord, nodeWord.data(), (size_t)N * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d + oWeight, nodeWeight.data(), (size_t)N * 8, hipMemcpyHostToDevice);
+  if (e != hipSuccess) { (void)hipFree(d); delete v; return ORBX_ERR_HIP; }
+  v->dev.childStart = (const int*)(d + oStart);
+  v->dev.childId = (const int*)(d + oId);
+  v->dev.childDesc = (const uint32_t*)(d + oDesc);
+  v->dev.nodeWord = (const uint32_t*)(d + oWord);
+  v->dev.nodeWeight = (const double*)(d + oWeight);
+  v->dev.nNodes = N; v->dev.L = L; v->dev.weighting = weighting;
+  *out = v;
+  return ORBX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int orbx_vocabulary_create(int k, int L, int scoring, int weighting, int n_nodes, const int32_t* parent,
+                           const uint8_t* is_leaf, const uint8_t* descriptors, const double* weights,
+                           int device_id, orbx_vocabulary** out) {
+  return build_vocabulary(k, L, scoring, weighting, n_nodes, parent, is_leaf, descriptors, weights, device_id, out);
+}
+
+int orbx_vocabulary_load_text(const char* path, int device_id, orbx_vocabulary** out) {
+  if (!path || !out) return ORBX_ERR_BAD_ARG;
+  *out = nullptr;
+  FILE* f = std::fopen(path, "r");
+  if (!f) return ORBX_ERR_BAD_ARG;
+  int k = 0, L = 0, n1 = 0, n2 = 0;
+  // header checks of vocabulary.cc:111-117
+  if (std::fscanf(f, "%d %d %d %d", &k, &L, &n1, &n2) != 4 || k < 0 || k > 20 || L < 1 || L > 10 || n1 < 0 ||
+      n1 > 5 || n2 < 0 || n2 > 3) {
+    std::fclose(f);
+    return ORBX_ERR_BAD_ARG;
+  }
+  std::vector<int32_t> parent;
+  std::vector<uint8_t> leaf, desc;
+  std::vector<double> weight;
+  bool ok = true;
+  for (;;) {
+    int pid, isLeaf;
+    if (std::fscanf(f, "%d %d", &pid, &isLeaf) != 2) break;   // end of file / a line without a node
+    for (int i = 0; i < 32 && ok; ++i) {
+      int b;
+      ok = std::fscanf(f, "%d", &b) == 1;
+      desc.push_back((uint8_t)b);
+    }
+    double w = 0;
+    ok = ok && std::fscanf(f, "%lf", &w) == 1;
+    if (!ok) break;
+    parent.push_back(pid);
+    leaf.push_back(isLeaf > 0 ? 1 : 0);
+    weight.push_back(w);
+  }
+  std::fclose(f);
+  if (!ok) return ORBX_ERR_BAD_ARG;
+  return build_vocabulary(k, L, n1, n2, (int)parent.size(), parent.data(), leaf.data(), desc.data(), weight.data(),
+                          device_id, out);
+}
+
+void orbx_vocabulary_destroy(orbx_vocabulary* v) {
+  if (!v) return;
+  (void)hipSetDevice(v->device);
+  if (v->d_block) (void)hipFree(v->d_block);
+  delete v;
+}
+
+int orbx_vocabulary_info(const orbx_vocabulary* v, int* k, int* L, int* n_nodes, int* n_words) {
+  if (!v) return ORBX_ERR_BAD_ARG;
+  if (k) *k = v->k;
+  if (L) *L = v->L;
+  if (n_nodes) *n_nodes = v->nNodes;
+  if (n_words) *n_words = v->nWords;
+  return ORBX_OK;
+}
+
+}  // extern "C"

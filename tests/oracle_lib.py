@@ -305,3 +305,46 @@ def search_by_projection_last(last_valid, uv, invz, last_octave, last_angle, las
                                             _p(b), _p(cs), _p(ent), _p(sf), th, int(forward), int(backward), mbf,
                                             int(check_orientation), _p(out))
     return n, out[:len(k)]
+
+
+class Vocabulary:
+    """The oracle's vocabulary (text file or arrays) and its transform()."""
+
+    def __init__(self, path=None, arrays=None):
+        L = lib()
+        L.orc_voc_create.restype = C.c_void_p
+        L.orc_voc_load_text.restype = C.c_void_p
+        if path is not None:
+            self.h = L.orc_voc_load_text(str(path).encode())
+        else:
+            k, depth, parent, leaf, desc, weight, weighting = arrays
+            self._keep = (np.ascontiguousarray(parent, np.int32), np.ascontiguousarray(leaf, np.uint8),
+                          np.ascontiguousarray(desc, np.uint8), np.ascontiguousarray(weight, np.float64))
+            self.h = L.orc_voc_create(int(k), int(depth), 0, int(weighting), len(self._keep[0]), _p(self._keep[0]),
+                                      _p(self._keep[1]), _p(self._keep[2]), _p(self._keep[3]))
+        if not self.h:
+            raise ValueError("vocabulary rejected")
+        self.h = C.c_void_p(self.h)
+
+    def __del__(self):
+        try:
+            lib().orc_voc_destroy(self.h)
+        except Exception:
+            pass
+
+    def info(self):
+        v = [C.c_int() for _ in range(4)]
+        lib().orc_voc_info(self.h, *[C.byref(x) for x in v])
+        return tuple(x.value for x in v)
+
+    def transform(self, desc, levelsup=4):
+        d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        n = max(len(d), 1)
+        wi, wv = np.zeros(n, np.uint32), np.zeros(n, np.float64)
+        ni, ns, ft = np.zeros(n, np.uint32), np.zeros(n + 1, np.int32), np.zeros(n, np.uint32)
+        nw, nn = C.c_int(), C.c_int()
+        st = lib().orc_bow_transform(self.h, _p(d), len(d), int(levelsup), _p(wi), _p(wv), C.byref(nw), _p(ni),
+                                     _p(ns), _p(ft), C.byref(nn))
+        assert st == 0
+        W, N = nw.value, nn.value
+        return wi[:W], wv[:W], ni[:N], ns[:N + 1], ft[:ns[N]]
