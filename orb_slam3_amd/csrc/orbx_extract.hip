@@ -393,6 +393,101 @@ __device__ __forceinline__ uint32_t quick_pair(const uint32_t (&R)[8][3], uint32
   return pk_max_i16(s1, s2);
 }
 
+// One detection pass of a cell at threshold tlow (steps 2-4 of the kernel below): quick
+// rejection, exact m for the survivors, suppression.  bitsHi collects the suppressed corners
+// with m > thHi, bitsLo (may be null) those with m > thLo.  Returns whether any lane set a
+// bitsHi bit (workgroup-wide).
+template <int TS>
+__device__ __forceinline__ bool fast_pass(const uint8_t* tile, uint8_t* mm, uint16_t* queue, int qcap, int cw,
+                                          int ch, int lane, int tlow, int thHi, uint32_t* bitsHi, int thLo,
+                                          uint32_t* bitsLo) {
+  const int np = cw * ch;
+  const int ngx = (cw + 3) >> 2, nry = (ch + 1) >> 1;
+  const int ntask = ngx * nry;
+  const float rngx = 1.0f / (float)ngx;
+  const float rcw = 1.0f / (float)cw;
+  const uint32_t tt = (uint32_t)tlow * 0x00010001u;
+  // ---- 2. quick rejection, 4 columns x 2 rows per lane ----------------------
+  int qn = 0;
+  for (int base = 0; base < ntask; base += 64) {
+    const int tsk = base + lane;
+    uint32_t flags = 0;
+    int x = 0, y = 0;
+    if (tsk < ntask) {
+      const int r = (int)(((float)tsk + 0.5f) * rngx);
+      x = (tsk - r * ngx) * 4;
+      y = r * 2;
+      uint32_t R[8][3];
+      const uint8_t* wp = tile + y * TS + x;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t* rp = (const uint32_t*)(wp + i * TS);
+        R[i][0] = rp[0]; R[i][1] = rp[1]; R[i][2] = rp[2];
+      }
+      const uint32_t e0 = quick_pair<3, 4>(R, tt);  // row y,   columns x, x+2
+      const uint32_t o0 = quick_pair<3, 5>(R, tt);  // row y,   columns x+1, x+3
+      const uint32_t e1 = quick_pair<4, 4>(R, tt);  // row y+1
+      const uint32_t o1 = quick_pair<4, 5>(R, tt);
+      flags |= ((int)(short)(e0 & 0xFFFF) > 0) ? 1u : 0u;
+      flags |= ((int)(short)(o0 & 0xFFFF) > 0) ? 2u : 0u;
+      flags |= ((int)e0 >> 16 > 0) ? 4u : 0u;
+      flags |= ((int)o0 >> 16 > 0) ? 8u : 0u;
+      flags |= ((int)(short)(e1 & 0xFFFF) > 0) ? 16u : 0u;
+      flags |= ((int)(short)(o1 & 0xFFFF) > 0) ? 32u : 0u;
+      flags |= ((int)e1 >> 16 > 0) ? 64u : 0u;
+      flags |= ((int)o1 >> 16 > 0) ? 128u : 0u;
+      // pixels outside the cell
+      uint32_t colmask = (x + 4 <= cw) ? 0xFu : ((1u << (cw - x)) - 1u);
+      uint32_t valid = colmask | ((y + 1 < ch) ? (colmask << 4) : 0u);
+      flags &= valid;
+    }
+    const int c = __popc(flags);
+    const int inc = wave_incl_scan(c);
+    int qpos = qn + inc - c;
+    while (flags) {
+      const int b = __ffs(flags) - 1;
+      flags &= flags - 1;
+      if (qpos < qcap) queue[qpos] = (uint16_t)(((y + (b >> 2)) << 7) | (x + (b & 3)));
+      ++qpos;
+    }
+    qn += __shfl(inc, 63, 64);
+  }
+  __syncthreads();
+
+  // ---- 3. exact m for the survivors -----------------------------------------
+  // (a cell with more survivors than the queue holds - noise-like content - is scored
+  // and suppressed pixel by pixel instead)
+  const bool overflow = qn > qcap;
+  const int nwork = overflow ? np : qn;
+  for (int qi = lane; qi < nwork; qi += 64) {
+    int x, y;
+    if (overflow) { y = (int)(((float)qi + 0.5f) * rcw); x = qi - y * cw; }
+    else { const int id = queue[qi]; x = id & 127; y = id >> 7; }
+    mm[(y + 1) * TS + x + 4] = (uint8_t)fast_m<TS>(tile + (y + 3) * TS + x + 4);
+  }
+  __syncthreads();
+
+  // ---- 4. suppression inside the cell ---------------------------------------
+  int anyHi = 0;
+  for (int qi = lane; qi < nwork; qi += 64) {
+    int x, y;
+    if (overflow) { y = (int)(((float)qi + 0.5f) * rcw); x = qi - y * cw; }
+    else { const int id = queue[qi]; x = id & 127; y = id >> 7; }
+    const uint8_t* q = mm + (y + 1) * TS + x + 4;
+    const int m = q[0];
+    if (m > tlow) {
+      const bool isMax = m > q[-1] && m > q[1] && m > q[-TS - 1] && m > q[-TS] && m > q[-TS + 1] &&
+                         m > q[TS - 1] && m > q[TS] && m > q[TS + 1];
+      if (isMax) {
+        const int p = y * cw + x;
+        if (m > thHi) { atomicOr(&bitsHi[p >> 5], 1u << (p & 31)); anyHi = 1; }
+        if (bitsLo && m > thLo) atomicOr(&bitsLo[p >> 5], 1u << (p & 31));
+      }
+    }
+  }
+  return __syncthreads_or(anyHi) != 0;
+}
+
 template <int TS>
 __global__ __launch_bounds__(64) void k_fast_cells(const Plan* __restrict__ plan,
                                                    const uint8_t* __restrict__ pyr,
@@ -450,93 +545,22 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Plan* __restrict__ plan
   }
   __syncthreads();
 
-  // ---- 2. quick rejection, 4 columns x 2 rows per lane ------------------------
+  // ---- 2.-4. detection at iniThFAST, and only in a cell that yields nothing there again at
+  // minThFAST (extractor.cc:789-807).  Survivors of the quick test are the pixels whose bound
+  // on m exceeds the threshold of the pass, so the first pass queues (and scores exactly) far
+  // fewer pixels than one pass at the lower threshold would; the few cells that need the
+  // second pass repeat the quick test.  Scores written by the first pass stay valid.
+  // When iniThFAST <= minThFAST one pass at iniThFAST serves both thresholds.
   const int ini = plan->ini_th, mn = plan->min_th;
-  const int tlow = min(ini, mn);
-  const uint32_t tt = (uint32_t)tlow * 0x00010001u;
-  const int ngx = (cw + 3) >> 2, nry = (ch + 1) >> 1;
-  const int ntask = ngx * nry;
   const int qcap = plan->fast_qcap;
-  const float rngx = 1.0f / (float)ngx;
-  int qn = 0;
-  for (int base = 0; base < ntask; base += 64) {
-    const int tsk = base + lane;
-    uint32_t flags = 0;
-    int x = 0, y = 0;
-    if (tsk < ntask) {
-      const int r = (int)(((float)tsk + 0.5f) * rngx);
-      x = (tsk - r * ngx) * 4;
-      y = r * 2;
-      uint32_t R[8][3];
-      const uint8_t* wp = tile + y * TS + x;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const uint32_t* rp = (const uint32_t*)(wp + i * TS);
-        R[i][0] = rp[0]; R[i][1] = rp[1]; R[i][2] = rp[2];
-      }
-      const uint32_t e0 = quick_pair<3, 4>(R, tt);  // row y,   columns x, x+2
-      const uint32_t o0 = quick_pair<3, 5>(R, tt);  // row y,   columns x+1, x+3
-      const uint32_t e1 = quick_pair<4, 4>(R, tt);  // row y+1
-      const uint32_t o1 = quick_pair<4, 5>(R, tt);
-      flags |= ((int)(short)(e0 & 0xFFFF) > 0) ? 1u : 0u;
-      flags |= ((int)(short)(o0 & 0xFFFF) > 0) ? 2u : 0u;
-      flags |= ((int)e0 >> 16 > 0) ? 4u : 0u;
-      flags |= ((int)o0 >> 16 > 0) ? 8u : 0u;
-      flags |= ((int)(short)(e1 & 0xFFFF) > 0) ? 16u : 0u;
-      flags |= ((int)(short)(o1 & 0xFFFF) > 0) ? 32u : 0u;
-      flags |= ((int)e1 >> 16 > 0) ? 64u : 0u;
-      flags |= ((int)o1 >> 16 > 0) ? 128u : 0u;
-      // pixels outside the cell
-      uint32_t colmask = (x + 4 <= cw) ? 0xFu : ((1u << (cw - x)) - 1u);
-      uint32_t valid = colmask | ((y + 1 < ch) ? (colmask << 4) : 0u);
-      flags &= valid;
-    }
-    const int c = __popc(flags);
-    const int inc = wave_incl_scan(c);
-    int qpos = qn + inc - c;
-    while (flags) {
-      const int b = __ffs(flags) - 1;
-      flags &= flags - 1;
-      if (qpos < qcap) queue[qpos] = (uint16_t)(((y + (b >> 2)) << 7) | (x + (b & 3)));
-      ++qpos;
-    }
-    qn += __shfl(inc, 63, 64);
-  }
-  __syncthreads();
-
-  // ---- 3. exact m for the survivors -------------------------------------------
-  // (a cell with more survivors than the queue holds - noise-like content - is scored
-  // and suppressed pixel by pixel instead)
-  const bool overflow = qn > qcap;
   const float rcw = 1.0f / (float)cw;
-  const int nwork = overflow ? np : qn;
-  for (int qi = lane; qi < nwork; qi += 64) {
-    int x, y;
-    if (overflow) { y = (int)(((float)qi + 0.5f) * rcw); x = qi - y * cw; }
-    else { const int id = queue[qi]; x = id & 127; y = id >> 7; }
-    mm[(y + 1) * TS + x + 4] = (uint8_t)fast_m<TS>(tile + (y + 3) * TS + x + 4);
+  bool useIni;
+  if (ini > mn) {
+    useIni = fast_pass<TS>(tile, mm, queue, qcap, cw, ch, lane, ini, ini, bitsIni, 0, nullptr);
+    if (!useIni) (void)fast_pass<TS>(tile, mm, queue, qcap, cw, ch, lane, mn, mn, bitsMin, 0, nullptr);
+  } else {
+    useIni = fast_pass<TS>(tile, mm, queue, qcap, cw, ch, lane, ini, ini, bitsIni, mn, bitsMin);
   }
-  __syncthreads();
-
-  // ---- 4. suppression inside the cell, both thresholds -------------------------
-  int anyIni = 0;
-  for (int qi = lane; qi < nwork; qi += 64) {
-    int x, y;
-    if (overflow) { y = (int)(((float)qi + 0.5f) * rcw); x = qi - y * cw; }
-    else { const int id = queue[qi]; x = id & 127; y = id >> 7; }
-    const uint8_t* q = mm + (y + 1) * TS + x + 4;
-    const int m = q[0];
-    if (m > tlow) {
-      const bool isMax = m > q[-1] && m > q[1] && m > q[-TS - 1] && m > q[-TS] && m > q[-TS + 1] &&
-                         m > q[TS - 1] && m > q[TS] && m > q[TS + 1];
-      if (isMax) {
-        const int p = y * cw + x;
-        if (m > ini) { atomicOr(&bitsIni[p >> 5], 1u << (p & 31)); anyIni = 1; }
-        if (m > mn) atomicOr(&bitsMin[p >> 5], 1u << (p & 31));
-      }
-    }
-  }
-  const bool useIni = __syncthreads_or(anyIni) != 0;
   const uint32_t* bits = useIni ? bitsIni : bitsMin;
 
   // ---- 5. ordered output ---------------------------------------------------------
