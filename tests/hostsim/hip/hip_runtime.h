@@ -134,7 +134,8 @@ const dim3& block_dim();
 const dim3& grid_dim();
 int lane_in_wave();
 
-void launch(const char* name, dim3 grid, dim3 block, size_t ldsBytes, const std::function<void()>& fn);
+void launch(const char* name, const void* kernel, dim3 grid, dim3 block, size_t ldsBytes,
+            const std::function<void()>& fn);
 
 template <class T> inline uint64_t to_bits(T v) {
   static_assert(sizeof(T) <= 8, "shuffle operand");
@@ -243,7 +244,7 @@ namespace hostsim {
 template <class K, class... A>
 inline void launch_kernel(const char* name, dim3 grid, dim3 block, size_t lds, K kern, A... args) {
   auto packed = std::make_tuple(args...);
-  launch(name, grid, block, lds, [&]() { std::apply(kern, packed); });
+  launch(name, (const void*)kern, grid, block, lds, [&]() { std::apply(kern, packed); });
 }
 }  // namespace hostsim
 #define hipLaunchKernelGGL(kern, grid, block, lds, stream, ...) \

@@ -34,6 +34,14 @@ static const size_t kStack = 256 * 1024;
 static const int kMaxThreads = 1024;
 static const size_t kLdsMax = 160 * 1024;
 
+// HOSTSIM_FILL=<byte>: what fresh device memory and LDS hold (default 0xA5 / 0xCD); results that
+// change with it depend on memory nobody wrote
+static int fill_byte(int dflt) {
+  static int v = [] { const char* e = getenv("HOSTSIM_FILL"); return e ? (int)strtol(e, nullptr, 0) & 0xFF : -1; }();
+  return v >= 0 ? v : dflt;
+}
+
+
 // ------------------------------------------------------------------------------------------
 // fibers
 // ------------------------------------------------------------------------------------------
@@ -286,7 +294,7 @@ static void run_block(Block* b, const char* name, uint3 bid, dim3 grid, dim3 blo
   b->fn = fn;
   const size_t ldsRounded = (ldsBytes + 15) & ~(size_t)15;
   b->dynLds = b->ldsRegion + kPage + kLdsMax - ldsRounded;
-  memset(b->dynLds, 0xCD, ldsRounded);   // LDS starts out undefined
+  memset(b->dynLds, fill_byte(0xCD), ldsRounded);   // LDS starts out undefined
   for (int w = 0; w < b->nwaves; ++w) {
     Wave& wv = b->waves[w];
     const int n = std::min(64, nt - 64 * w);
@@ -343,9 +351,29 @@ static int worker_count() {
 
 static std::atomic<long> g_launches{0};
 
-void launch(const char* name, dim3 grid, dim3 block, size_t ldsBytes, const std::function<void()>& fn) {
+// dynamic LDS a kernel may be launched with: 64 KB unless hipFuncSetAttribute raised it
+static std::mutex g_attrMu;
+static std::map<const void*, size_t> g_maxDynLds;
+
+void launch(const char* name, const void* kernel, dim3 grid, dim3 block, size_t ldsBytes,
+            const std::function<void()>& fn) {
   const long nblocks = (long)grid.x * grid.y * grid.z;
   const int nt = (int)(block.x * block.y * block.z);
+  if (grid.y > 65535u || grid.z > 65535u) {
+    fprintf(stderr, "hostsim: %s: grid (%u,%u,%u) exceeds the 65535 limit of the y / z dimensions\n", name, grid.x,
+            grid.y, grid.z);
+    abort();
+  }
+  {
+    std::lock_guard<std::mutex> lk(g_attrMu);
+    auto it = g_maxDynLds.find(kernel);
+    const size_t allowed = it == g_maxDynLds.end() ? 64 * 1024 : std::max<size_t>(64 * 1024, it->second);
+    if (ldsBytes > allowed) {
+      fprintf(stderr, "hostsim: %s: %zu bytes of dynamic LDS without hipFuncSetAttribute (allowed %zu)\n", name,
+              ldsBytes, allowed);
+      abort();
+    }
+  }
   if (nblocks <= 0 || nt <= 0) { fprintf(stderr, "hostsim: empty launch of %s\n", name); abort(); }
   if (nt > kMaxThreads) { fprintf(stderr, "hostsim: %s: %d threads per workgroup\n", name, nt); abort(); }
   if (ldsBytes > kLdsMax) { fprintf(stderr, "hostsim: %s: %zu bytes of dynamic LDS\n", name, ldsBytes); abort(); }
@@ -409,7 +437,7 @@ static void* guarded_alloc(size_t n) {
   mprotect(m, kPage, PROT_NONE);
   mprotect(m + kPage + bodyPages, kPage, PROT_NONE);
   uint8_t* user = guard_at_start() ? m + kPage : m + kPage + bodyPages - body;
-  memset(m + kPage, 0xA5, bodyPages);   // device memory starts out undefined
+  memset(m + kPage, fill_byte(0xA5), bodyPages);   // device memory starts out undefined
   std::lock_guard<std::mutex> lk(g_allocMu);
   g_allocs[(uintptr_t)user] = Alloc{m, total, n};
   return user;
@@ -555,6 +583,13 @@ hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
   *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
   return hipSuccess;
 }
-hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+hipError_t hipFuncSetAttribute(const void* f, hipFuncAttribute a, int v) {
+  if (a == hipFuncAttributeMaxDynamicSharedMemorySize) {
+    if (v < 0 || (size_t)v > hostsim::kLdsMax) return hipErrorInvalidValue;
+    std::lock_guard<std::mutex> lk(hostsim::g_attrMu);
+    hostsim::g_maxDynLds[f] = (size_t)v;
+  }
+  return hipSuccess;
+}
 
 }  // extern "C"
