@@ -64,6 +64,23 @@ def test_bow_vocabulary_from_arrays_and_repeated_words(oracle):
     assert 1 <= n <= 9
 
 
+def test_bow_large_capacity(oracle):
+    """10000 features per frame: the sort keys no longer fit LDS and live in a device workspace."""
+    k, L = 10, 3
+    arrays = voc_util.make_vocabulary(k, L, seed=77)
+    voc = bow.ORBVocabulary.from_arrays(k, L, *arrays)
+    ovoc = oracle.Vocabulary(arrays=(k, L) + arrays + (0,))
+    B = 2
+    ex = orbx.ORBextractor(10000, 1.2, 8, 20, 7, max_batch=B)
+    assert ex.max_keypoints() > 8192
+    frames = [orbx.textured_frame(500 + i, 1241, 376) for i in range(B)]
+    res = ex.extract_batch(frames, (0, 0))
+    bow.transform_batch(ex, voc, B, 2)
+    for f in range(B):
+        assert len(res[f][2]) > 4000
+        assert check_frame(ex, f, ovoc, res[f][2], 2) > 300
+
+
 def test_bow_argument_errors(tmp_path):
     from orb_slam3_amd._lib import OrbxError, ORBX_ERR_BAD_ARG, ORBX_ERR_UNSUPPORTED, ORBX_ERR_BATCH
     arrays = voc_util.make_vocabulary(4, 2, seed=1)
