@@ -182,6 +182,58 @@ def stereo_bench(torch, orbx, dev, local_rank, batch=128, reps=5):
             "match_stage_ms_per_step": sec_match * 1e3, "matches_per_pair": nmatch}
 
 
+def bow_bench(torch, orbx, dev, local_rank, batch=256, reps=5, k=10, depth=5):
+    """Secondary metric (opt-in): frames/s of Frame::ComputeBoW on device-resident descriptors,
+    synthetic vocabulary of k^depth words (children = bit-flipped copies of their parent)."""
+    from tests import voc_util
+    arrays = voc_util.make_vocabulary(k, depth, seed=1)
+    voc = orbx.bow.ORBVocabulary.from_arrays(k, depth, *arrays, device=local_rank)
+    distinct = 8
+    imgs = np.stack([orbx.textured_frame(700 + i, W, H) for i in range(distinct)])
+    d = torch.from_numpy(np.tile(imgs, ((batch + distinct - 1) // distinct, 1, 1))[:batch].copy()).to(dev)
+    ex = orbx.ORBextractor(*PARAMS, device=local_rank, max_batch=batch)
+    ex.extract_batch_device(d.data_ptr(), batch, W, H, W, (0, 1000))
+    orbx.bow.transform_batch(ex, voc, batch, 4)
+    ex.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        orbx.bow.transform_batch(ex, voc, batch, 4)
+    ex.sync()
+    sec = (time.perf_counter() - t0) / reps
+    words = float(np.mean([len(orbx.bow.download(ex, f)[0]) for f in range(min(batch, 4))]))
+    return {"metric": "ComputeBoW frames/s (transform only, descriptors resident)", "value": batch / sec,
+            "unit": "frames/s", "frames_per_step": batch, "ms_per_step": sec * 1e3,
+            "vocabulary": {"k": k, "L": depth, "nodes": voc.info()[2], "words": voc.info()[3]},
+            "words_per_frame": words}
+
+
+def guided_bench(torch, orbx, dev, local_rank, reps=20):
+    """Secondary metric (opt-in): latency of one SearchByProjection(CurrentFrame, LastFrame) call
+    (host arrays in, assignments out) on a 752x480 frame with 1000 features, last frame = the same
+    scene shifted by 6 pixels."""
+    shift = 6
+    wide = orbx.textured_frame(41, W + shift, H)
+    a, b = np.ascontiguousarray(wide[:, shift:]), np.ascontiguousarray(wide[:, :W])
+    exa = orbx.ORBextractor(*PARAMS, device=local_rank)
+    _, ka, da = exa(a, None, (0, 0))
+    exb = orbx.ORBextractor(*PARAMS, device=local_rank)
+    exb(b, None, (0, 0))
+    orbx.grid.frame_grid_batch(exb, 1, None, orbx.grid.image_bounds(None, W, H))
+    rng = np.random.default_rng(0)
+    n_last = len(ka)
+    uv = np.stack([ka["x"] + shift + rng.uniform(-2, 2, n_last), ka["y"] + rng.uniform(-2, 2, n_last)], 1)
+    args = (exb, 0, np.ones(n_last, np.uint8), uv.astype(np.float32), np.full(n_last, 0.5, np.float32),
+            ka["octave"], ka["angle"], da, np.ones(n_last, np.uint8))
+    nm, _, rounds = orbx.guided.search_by_projection_last(*args, th=15.0)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        orbx.guided.search_by_projection_last(*args, th=15.0)
+    sec = (time.perf_counter() - t0) / reps
+    return {"metric": "SearchByProjection(Frame, LastFrame) ms per call (host arrays in and out)",
+            "value": sec * 1e3, "unit": "ms", "higher_is_better": False, "queries": n_last, "matches": nm,
+            "rounds": rounds}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -191,6 +243,8 @@ def main():
     ap.add_argument("--no-match", action="store_true", help="skip the Hamming 2-NN leg")
     ap.add_argument("--stereo", action="store_true",
                     help="add the stereo leg (752x480 pairs, 2x1200 kp: both extractions + ComputeStereoMatches)")
+    ap.add_argument("--bow", action="store_true", help="add the bag-of-words leg (frames/s of ComputeBoW)")
+    ap.add_argument("--guided", action="store_true", help="add the guided-matching leg (ms per SearchByProjection call)")
     ap.add_argument("--distinct", type=int, default=32, help="distinct synthetic frames (tiled to the batch)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--stage-times", action="store_true",
@@ -301,6 +355,10 @@ def main():
             out["hamming"] = hamming_bench(torch, orbx, dev)
         if args.stereo:
             out["stereo"] = stereo_bench(torch, orbx, dev, local_rank)
+        if args.bow:
+            out["bow"] = bow_bench(torch, orbx, dev, local_rank)
+        if args.guided:
+            out["guided"] = guided_bench(torch, orbx, dev, local_rank)
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames)
             out["gpu_over_cpu"] = fps / out["cpu_baseline"]["value"]
