@@ -12,6 +12,10 @@
  *                                 (core/src/Frame.cc:831-996) on two extractors
  *   orbx_cv::KnnMatch2            BFMatcher(NORM_HAMMING).knnMatch(q, t, m, 2)
  *                                 (core/src/Frame.cc:1177)
+ *   orbx_cv::ORBVocabulary        the vocabulary in device memory, loaded from the text format
+ *                                 of ORBVocabulary::loadFromText (core/lib/ORB/vocabulary.cc:96-160)
+ *   orbx_cv::ComputeBoW           the body of Frame::ComputeBoW (core/src/Frame.cc:764-769) on an
+ *                                 extractor's last frame, into DBoW2-shaped maps
  * A source tree that wants the drop-in adds
  *   namespace ORB_SLAM3 { using ORBextractor = orbx_cv::ORBextractor; }
  * in place of its extractor.h.  Needs <opencv2/core.hpp>; link with -lorbx_hip.
@@ -169,6 +173,54 @@ inline void KnnMatch2(const cv::Mat& query, const cv::Mat& train,
     for (int e = 0; e < 2; ++e)
       if (idx[2 * (size_t)i + e] != 0xFFFFFFFFu)
         matches[i].push_back(cv::DMatch(i, (int)idx[2 * (size_t)i + e], (float)dist[2 * (size_t)i + e]));
+}
+
+// The vocabulary tree in device memory.  load() takes the text format ("k L scoring weighting",
+// then one node per line: parent, leaf flag, 32 descriptor bytes, weight).
+class ORBVocabulary {
+ public:
+  ORBVocabulary() {}
+  explicit ORBVocabulary(const std::string& filename, int device = 0) { load(filename, device); }
+  ~ORBVocabulary() { orbx_vocabulary_destroy(voc_); }
+  ORBVocabulary(const ORBVocabulary&) = delete;
+  ORBVocabulary& operator=(const ORBVocabulary&) = delete;
+  bool load(const std::string& filename, int device = 0) {
+    orbx_vocabulary_destroy(voc_);
+    voc_ = nullptr;
+    return orbx_vocabulary_load_text(filename.c_str(), device, &voc_) == ORBX_OK;
+  }
+  bool empty() const { return voc_ == nullptr; }
+  const orbx_vocabulary* handle() const { return voc_; }
+
+ private:
+  orbx_vocabulary* voc_ = nullptr;
+};
+
+// After extractor(image, ...): mBowVec / mFeatVec of that frame.  BowMap is a
+// std::map<unsigned, double> (DBoW2::BowVector derives from it), FeatMap a
+// std::map<unsigned, std::vector<unsigned>> (DBoW2::FeatureVector); entries are inserted in key
+// order, the order the reference's maps iterate in.
+template <class BowMap, class FeatMap>
+inline void ComputeBoW(ORBextractor& extractor, const ORBVocabulary& voc, BowMap& mBowVec, FeatMap& mFeatVec,
+                       int levelsup = 4) {
+  mBowVec.clear();
+  mFeatVec.clear();
+  if (voc.empty()) return;
+  throw_on(orbx_bow_transform_batch_device(extractor.handle(), voc.handle(), 1, levelsup),
+           "orbx_bow_transform_batch_device");
+  const int cap = orbx_max_keypoints(extractor.handle());
+  std::vector<uint32_t> words(cap), nodes(cap), feats(cap);
+  std::vector<double> values(cap);
+  std::vector<int32_t> start(cap + 1);
+  int nw = 0, nn = 0;
+  throw_on(orbx_bow_download(extractor.handle(), 0, words.data(), values.data(), &nw, nodes.data(), start.data(),
+                             feats.data(), &nn, cap), "orbx_bow_download");
+  for (int i = 0; i < nw; ++i) mBowVec.insert(mBowVec.end(), typename BowMap::value_type(words[i], values[i]));
+  for (int r = 0; r < nn; ++r) {
+    typename FeatMap::iterator it =
+        mFeatVec.insert(mFeatVec.end(), typename FeatMap::value_type(nodes[r], typename FeatMap::mapped_type()));
+    it->second.assign(feats.begin() + start[r], feats.begin() + start[r + 1]);
+  }
 }
 
 }  // namespace orbx_cv

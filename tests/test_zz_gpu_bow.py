@@ -100,3 +100,21 @@ def test_bow_argument_errors(tmp_path):
     with pytest.raises(OrbxError) as e:
         bow.transform_batch(ex, voc, 2, 4)    # only one frame was extracted
     assert e.value.status == ORBX_ERR_BATCH
+
+
+@pytest.mark.needs_real_device
+def test_cv_adaptor_bow_binary(tmp_path):
+    """orbx_cv::ORBVocabulary / ComputeBoW of include/orbx_cv.hpp fill DBoW2-shaped maps with exactly
+    what the C ABI returns.  The binary is built by __graft_entry__.build() against the test-only
+    OpenCV stand-in in tests/cpp/cvstub and links the real library."""
+    import os
+    import subprocess
+    arrays = voc_util.make_vocabulary(10, 3, seed=3)
+    path = tmp_path / "voc.txt"
+    voc_util.write_text(path, 10, 3, arrays)
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "_build", "test_adaptor_bow")
+    if not os.path.exists(exe):
+        import __graft_entry__
+        __graft_entry__.build_adaptor_test()
+    out = subprocess.run([exe, str(path)], capture_output=True, text=True, timeout=100)
+    assert out.returncode == 0 and out.stdout.startswith("ok"), out.stdout + out.stderr
