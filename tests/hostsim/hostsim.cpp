@@ -315,9 +315,13 @@ static void run_block(Block* b, const char* name, uint3 bid, dim3 grid, dim3 blo
     prepare_fiber(b, i);
   }
   tl_block = b;
+  // HOSTSIM_ORDER=reverse runs the threads of a workgroup from the last to the first: code whose
+  // result depends on which thread gets to a point first (a missing barrier) changes its output
+  static const bool reverseOrder = [] { const char* e = getenv("HOSTSIM_ORDER"); return e && !strcmp(e, "reverse"); }();
   while (b->alive > 0) {
     bool progressed = false;
-    for (int i = 0; i < nt; ++i) {
+    for (int k = 0; k < nt; ++k) {
+      const int i = reverseOrder ? nt - 1 - k : k;
       Lane& l = b->lanes[i];
       if (l.done) continue;
       if (l.waitOn && *l.waitOn == l.waitVal) continue;
