@@ -369,6 +369,10 @@ int orbx_extractor::ensurePlan(int W, int H) {
   hp.fast_mm_rows = chMax + 2;
   hp.fast_qcap = std::min(512, (cwMax * chMax + 7) / 8 * 8);  // survivors queued per cell; more -> per-pixel path
   hp.fast_words = (cwMax * chMax + 31) / 32;
+  {
+    const char* e = std::getenv("ORBX_FAST_SINGLE_PASS");   // timing knob, results do not change
+    hp.fast_two_pass = (e && e[0] == '1') ? 0 : 1;
+  }
   hp.oct_nodes_cap = nodesCap;
   hp.oct_cells_max = cellsMax;
   {

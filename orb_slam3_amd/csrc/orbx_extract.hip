@@ -550,16 +550,17 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Plan* __restrict__ plan
   // on m exceeds the threshold of the pass, so the first pass queues (and scores exactly) far
   // fewer pixels than one pass at the lower threshold would; the few cells that need the
   // second pass repeat the quick test.  Scores written by the first pass stay valid.
-  // When iniThFAST <= minThFAST one pass at iniThFAST serves both thresholds.
+  // When iniThFAST <= minThFAST (or the plan asks for it) one pass at the lower threshold serves
+  // both.
   const int ini = plan->ini_th, mn = plan->min_th;
   const int qcap = plan->fast_qcap;
   const float rcw = 1.0f / (float)cw;
   bool useIni;
-  if (ini > mn) {
+  if (ini > mn && plan->fast_two_pass) {
     useIni = fast_pass<TS>(tile, mm, queue, qcap, cw, ch, lane, ini, ini, bitsIni, 0, nullptr);
     if (!useIni) (void)fast_pass<TS>(tile, mm, queue, qcap, cw, ch, lane, mn, mn, bitsMin, 0, nullptr);
   } else {
-    useIni = fast_pass<TS>(tile, mm, queue, qcap, cw, ch, lane, ini, ini, bitsIni, mn, bitsMin);
+    useIni = fast_pass<TS>(tile, mm, queue, qcap, cw, ch, lane, min(ini, mn), ini, bitsIni, mn, bitsMin);
   }
   const uint32_t* bits = useIni ? bitsIni : bitsMin;
 

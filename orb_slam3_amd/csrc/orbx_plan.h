@@ -84,6 +84,9 @@ struct Plan {
   // k_fast_cells LDS geometry (max over levels): row stride, tile rows, m-map rows,
   // survivor queue entries, bit-mask words
   int fast_ts, fast_tile_rows, fast_mm_rows, fast_qcap, fast_words;
+  // 1: detect at iniThFAST first and at minThFAST only in cells that found nothing; 0: one pass
+  // at the lower threshold that serves both (same results; kept switchable for timing)
+  int fast_two_pass;
   int oct_nodes_cap;     // quadtree node slots (max over levels)
   int oct_cells_max;     // max cells in one level
   int oct_keys_lds;      // keys per LDS key buffer of k_octree (0 = always use global memory)
