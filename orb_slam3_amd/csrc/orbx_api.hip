@@ -575,6 +575,12 @@ int orbx_extractor::run(const uint8_t* d_images, int istride, size_t iframe, int
   evValid = prof;
   HIP_TRY(hipGetLastError());
   lastFrames = nframes;
+  // results derived from the previous extraction (stereo association, frame grid, bag of words)
+  // describe keypoints that no longer exist: their download / query calls fail until the
+  // corresponding call has run again
+  stereoFrames = 0;
+  gridFrames = 0;
+  bowFrames = 0;
   std::fill(h_pyr_valid.begin(), h_pyr_valid.end(), 0);
   return ORBX_OK;
 }

@@ -149,3 +149,21 @@ def test_guided_argument_errors():
         guided.search_by_projection_last(ex, 0, np.ones(1, np.uint8), np.zeros((1, 2)), np.ones(1),
                                          np.array([9]), np.zeros(1), np.zeros((1, 32)), np.ones(1))
     assert e.value.status == ORBX_ERR_BAD_ARG
+
+
+def test_results_derived_from_an_extraction_expire_with_it():
+    """A new extraction on the handle invalidates the frame grid (and with it the guided matchers)
+    until the grid call has run again."""
+    from orb_slam3_amd._lib import OrbxError, ORBX_ERR_BAD_ARG
+    ex = orbx.ORBextractor(300, 1.2, 4, 20, 7)
+    img = orbx.textured_frame(2, 376, 240)
+    ex(img, None, (0, 0))
+    b = grid.image_bounds(None, 376, 240)
+    grid.frame_grid_batch(ex, 1, None, b)
+    grid.features_in_area(ex, 0, np.array([[100, 100, 20, -1, -1]], np.float32))
+    ex(img, None, (0, 0))
+    with pytest.raises(OrbxError) as e:
+        grid.features_in_area(ex, 0, np.array([[100, 100, 20, -1, -1]], np.float32))
+    assert e.value.status == ORBX_ERR_BAD_ARG
+    grid.frame_grid_batch(ex, 1, None, b)
+    grid.features_in_area(ex, 0, np.array([[100, 100, 20, -1, -1]], np.float32))
