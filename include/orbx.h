@@ -217,6 +217,11 @@ int orbx_stereo_download(orbx_extractor* left, int frame, float* uright, float* 
 int orbx_stereo_match(orbx_extractor* left, orbx_extractor* right, float mbf, float mb,
                       float* uright, float* depth, int cap, int* n_out);
 
+/* Results derived from an extraction (stereo association, frame grid, bag of
+ * words) belong to the keypoints of that extraction: the next extraction on the
+ * handle invalidates them, and their download / query calls return
+ * ORBX_ERR_BAD_ARG until the deriving call has run again. */
+
 /* ---- frame grid on device-resident extractions ------------------------------ */
 /* Pinhole camera with OpenCV's radial-tangential coefficients, as Frame holds
  * them in mK and mDistCoef (k3 = 0 when the settings give four coefficients). */
