@@ -380,6 +380,12 @@ int orbx_extractor::ensurePlan(int W, int H) {
     const long fixed = (long)nodesCap * 86 + (long)(cellsMax + 1) * 4 + 64;
     const long keys = (32 * 1024 - fixed) / 8;
     hp.oct_keys_lds = keys < 256 ? 0 : (int)std::min(keys, 8192L);
+    // timing knob: fewer LDS keys per wave = more waves per CU, but more levels partition their
+    // keys in the global buffers instead (results do not change)
+    if (const char* e = std::getenv("ORBX_OCT_KEYS_LDS")) {
+      const long v = std::strtol(e, nullptr, 10);
+      if (v >= 0 && v <= 8192) hp.oct_keys_lds = (int)v;
+    }
     hp.oct_ws_bytes = 0;
     if (orbx::octree_lds_bytes(hp) > 96 * 1024) {
       hp.oct_keys_lds = 0;
