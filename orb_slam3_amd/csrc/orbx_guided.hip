@@ -16,7 +16,10 @@
 //
 // One workgroup per call: the work is a few thousand window walks of a few dozen 256-bit
 // distances each, the rounds need workgroup-wide barriers, and the caller (Tracking) has one
-// frame at a time.  Latency-bound by design.
+// frame at a time.  Latency-bound by design: the first round walks the grid (chains of
+// dependent loads: cell list -> keypoint -> descriptor) and remembers every query's candidates
+// with their distances; the later rounds only re-read that list (queries with more than
+// GUIDED_CACHE candidates walk again).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -28,7 +31,8 @@
 #define HISTO_LENGTH 30   /* ORBmatcher::HISTO_LENGTH, matcher.cc:36 */
 #define TH_HIGH 100       /* matcher.cc:34 */
 #define TH_LOW 50         /* matcher.cc:35 */
-#define GUIDED_THREADS 256
+#define GUIDED_THREADS 1024   /* one query per thread for a usual frame */
+#define GUIDED_CACHE 48       /* candidates remembered per query (packed distance << 16 | keypoint) */
 
 namespace orbx {
 
@@ -143,17 +147,21 @@ struct ProjectionArgs {
   float scale[ORBX_MAX_LEVELS];
   float th, mbf;
   int forward, backward, checkOrientation;
-  // work arrays: two generations of choices (nLast) and of closing times (n)
+  // work arrays: two generations of choices (nLast) and of closing times (n); the candidate
+  // lists of round 1, slot-major ([GUIDED_CACHE][nLast]) so that a wave reads them coalesced
   int* choice[2];
   int* closedAt[2];
+  uint32_t* cand;
+  int* candCount;          // per query: candidates cached, or -1 = too many, walk again
   // results
   int* assigned;           // n
   int* summary;            // [0] nmatches, [1] rounds
 };
 
 // choice of last-frame keypoint i given the closing times of the previous round
-// (matcher.cc:1607-1690): the keypoint it matches, or -1
-__device__ int projection_choice(const ProjectionArgs& a, int i, const int* closedAt) {
+// (matcher.cc:1607-1690): the keypoint it matches, or -1.  store: remember the candidates.
+__device__ int projection_choice(const ProjectionArgs& a, int i, const int* closedAt, bool store) {
+  if (store) a.candCount[i] = 0;
   if (!a.lastValid[i]) return -1;
   const float invzc = a.invz[i];
   if (invzc < 0) return -1;
@@ -170,11 +178,8 @@ __device__ int projection_choice(const ProjectionArgs& a, int i, const int* clos
 #pragma unroll
   for (int w = 0; w < 8; ++w) dMP[w] = a.lastDesc[(size_t)i * 8 + w];
   const float ur = __fsub_rn(u, __fmul_rn(a.mbf, invzc));
-  int bestDist = 256, bestIdx2 = -1;
+  int bestDist = 256, bestIdx2 = -1, k = 0;
   for_each_in_area(a.grid, u, v, radius, minLevel, maxLevel, [&](int i2) {
-    // closed: the keypoint holds a map point with observations, from the start (-1) or
-    // since an earlier query put one there (matcher.cc:1663-1666)
-    if (coherent_load(&closedAt[i2]) < i) return;
     if (a.uRight) {
       const float r2 = a.uRight[i2];
       if (r2 > 0) {
@@ -183,8 +188,28 @@ __device__ int projection_choice(const ProjectionArgs& a, int i, const int* clos
       }
     }
     const int dist = hamming_reg(dMP, a.desc + (size_t)i2 * 8);
+    if (store) {
+      if (k < GUIDED_CACHE) a.cand[(size_t)k * a.nLast + i] = ((uint32_t)dist << 16) | (uint32_t)i2;
+      ++k;
+    }
+    // closed: the keypoint holds a map point with observations, from the start (-1) or
+    // since an earlier query put one there (matcher.cc:1663-1666)
+    if (coherent_load(&closedAt[i2]) < i) return;
     if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
   });
+  if (store) a.candCount[i] = k <= GUIDED_CACHE ? k : -1;
+  return bestDist <= TH_HIGH ? bestIdx2 : -1;
+}
+
+// the same decision from the remembered candidates (same order, so the same ties)
+__device__ int projection_choice_cached(const ProjectionArgs& a, int i, const int* closedAt, int cnt) {
+  int bestDist = 256, bestIdx2 = -1;
+  for (int k = 0; k < cnt; ++k) {
+    const uint32_t e = a.cand[(size_t)k * a.nLast + i];
+    const int i2 = (int)(e & 0xFFFFu), dist = (int)(e >> 16);
+    if (coherent_load(&closedAt[i2]) < i) continue;
+    if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+  }
   return bestDist <= TH_HIGH ? bestIdx2 : -1;
 }
 
@@ -208,7 +233,13 @@ __global__ __launch_bounds__(GUIDED_THREADS) void k_search_by_projection_last(Pr
     int* bNew = a.closedAt[cur ^ 1];
     int changed = 0;
     for (int i = tid; i < a.nLast; i += GUIDED_THREADS) {
-      const int c = projection_choice(a, i, bPrev);
+      int c;
+      if (rounds == 0) {
+        c = projection_choice(a, i, bPrev, true);
+      } else {
+        const int cnt = a.candCount[i];
+        c = cnt >= 0 ? projection_choice_cached(a, i, bPrev, cnt) : projection_choice(a, i, bPrev, false);
+      }
       cNew[i] = c;
       changed |= (c != cPrev[i]) ? 1 : 0;
     }
@@ -278,32 +309,57 @@ struct InitArgs {
   int* claimDist[2];
   int* head;               // n2; reused as owner at the end
   int* next;               // n1
+  uint32_t* cand;          // [GUIDED_CACHE][n1], as above
+  int* candCount;          // n1
   // results
   int* matches12;          // n1
   int* summary;            // [0] nmatches, [1] rounds
 };
 
-// claim of query i1 given the claims of the previous round (matcher.cc:638-704)
-__device__ void init_choice(const InitArgs& a, int i1, const int* claimDistPrev, int* kpOut, int* distOut) {
+// vMatchedDistance[i2] as query i1 meets it: the smallest distance accepted by an earlier query
+__device__ __forceinline__ int init_seen(const InitArgs& a, int i1, int i2, const int* claimDistPrev) {
+  int seen = 0x7fffffff;
+  for (int j = coherent_load(&a.head[i2]); j >= 0; j = a.next[j])
+    if (j < i1) seen = min(seen, claimDistPrev[j]);
+  return seen;
+}
+
+// claim of query i1 given the claims of the previous round (matcher.cc:638-704).
+// mode 0: walk the window and remember the candidates; 1: walk only; 2: use the remembered ones.
+__device__ void init_choice(const InitArgs& a, int i1, const int* claimDistPrev, int mode, int* kpOut, int* distOut) {
   *kpOut = -1;
   *distOut = 0x7fffffff;
-  const GKP kp1 = a.K1[i1];
-  const int level1 = kp1.octave;
-  if (level1 > 0) return;
-  uint32_t d1[8];
-#pragma unroll
-  for (int w = 0; w < 8; ++w) d1[w] = a.desc1[(size_t)i1 * 8 + w];
   int bestDist = 0x7fffffff, bestDist2 = 0x7fffffff, bestIdx2 = -1;
-  for_each_in_area(a.grid, a.prevMatched[2 * i1], a.prevMatched[2 * i1 + 1], a.window, level1, level1, [&](int i2) {
-    const int dist = hamming_reg(d1, a.desc2 + (size_t)i2 * 8);
-    // vMatchedDistance[i2] as query i1 meets it: the smallest distance accepted by an earlier query
-    int seen = 0x7fffffff;
-    for (int j = coherent_load(&a.head[i2]); j >= 0; j = a.next[j])
-      if (j < i1) seen = min(seen, claimDistPrev[j]);
-    if (seen <= dist) return;
+  auto consider = [&](int i2, int dist) {
+    if (init_seen(a, i1, i2, claimDistPrev) <= dist) return;
     if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
     else if (dist < bestDist2) { bestDist2 = dist; }
-  });
+  };
+  if (mode == 2) {
+    const int cnt = a.candCount[i1];
+    for (int k = 0; k < cnt; ++k) {
+      const uint32_t e = a.cand[(size_t)k * a.n1 + i1];
+      consider((int)(e & 0xFFFFu), (int)(e >> 16));
+    }
+  } else {
+    if (mode == 0) a.candCount[i1] = 0;
+    const GKP kp1 = a.K1[i1];
+    const int level1 = kp1.octave;
+    if (level1 > 0) return;
+    uint32_t d1[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) d1[w] = a.desc1[(size_t)i1 * 8 + w];
+    int k = 0;
+    for_each_in_area(a.grid, a.prevMatched[2 * i1], a.prevMatched[2 * i1 + 1], a.window, level1, level1, [&](int i2) {
+      const int dist = hamming_reg(d1, a.desc2 + (size_t)i2 * 8);
+      if (mode == 0) {
+        if (k < GUIDED_CACHE) a.cand[(size_t)k * a.n1 + i1] = ((uint32_t)dist << 16) | (uint32_t)i2;
+        ++k;
+      }
+      consider(i2, dist);
+    });
+    if (mode == 0) a.candCount[i1] = k <= GUIDED_CACHE ? k : -1;
+  }
   if (bestDist <= TH_LOW && (float)bestDist < __fmul_rn((float)bestDist2, a.nnratio)) {
     *kpOut = bestIdx2;
     *distOut = bestDist;
@@ -335,7 +391,7 @@ __global__ __launch_bounds__(GUIDED_THREADS) void k_search_for_initialization(In
     int changed = 0;
     for (int i = tid; i < a.n1; i += GUIDED_THREADS) {
       int c, d;
-      init_choice(a, i, dPrev, &c, &d);
+      init_choice(a, i, dPrev, rounds == 0 ? 0 : (a.candCount[i] >= 0 ? 2 : 1), &c, &d);
       cNew[i] = c;
       dNew[i] = d;
       changed |= (c != cPrev[i]) ? 1 : 0;
@@ -395,8 +451,8 @@ static GridView make_grid(const float* d_kpsUn, const int* d_cellStart, const in
 }
 
 // work memory either launcher needs beyond its inputs and outputs, in ints
-size_t projection_work_ints(int nLast, int n) { return 2 * (size_t)nLast + 2 * (size_t)n; }
-size_t init_work_ints(int n1, int n2) { return 5 * (size_t)n1 + (size_t)n2; }
+size_t projection_work_ints(int nLast, int n) { return (3 + GUIDED_CACHE) * (size_t)nLast + 2 * (size_t)n; }
+size_t init_work_ints(int n1, int n2) { return (6 + GUIDED_CACHE) * (size_t)n1 + (size_t)n2; }
 
 void launch_search_by_projection_last(const uint8_t* d_lastValid, const float* d_uv, const float* d_invz,
                                       const int* d_lastOctave, const float* d_lastAngle, const uint8_t* d_lastDesc,
@@ -415,6 +471,8 @@ void launch_search_by_projection_last(const uint8_t* d_lastValid, const float* d
   a.th = th; a.mbf = mbf; a.forward = forward; a.backward = backward; a.checkOrientation = checkOrientation;
   a.choice[0] = d_work; a.choice[1] = d_work + nLast;
   a.closedAt[0] = d_work + 2 * (size_t)nLast; a.closedAt[1] = a.closedAt[0] + n;
+  a.candCount = a.closedAt[1] + n;
+  a.cand = (uint32_t*)(a.candCount + nLast);
   a.assigned = d_assigned; a.summary = d_summary;
   hipLaunchKernelGGL(k_search_by_projection_last, dim3(1), dim3(GUIDED_THREADS), 0, s, a);
 }
@@ -432,7 +490,9 @@ void launch_search_for_initialization(const float* d_kps1Un, const uint8_t* d_de
   a.claim[0] = d_work; a.claim[1] = d_work + n1;
   a.claimDist[0] = d_work + 2 * (size_t)n1; a.claimDist[1] = d_work + 3 * (size_t)n1;
   a.next = d_work + 4 * (size_t)n1;
-  a.head = d_work + 5 * (size_t)n1;
+  a.candCount = d_work + 5 * (size_t)n1;
+  a.cand = (uint32_t*)(d_work + 6 * (size_t)n1);
+  a.head = d_work + (6 + GUIDED_CACHE) * (size_t)n1;
   a.matches12 = d_matches12; a.summary = d_summary;
   hipLaunchKernelGGL(k_search_for_initialization, dim3(1), dim3(GUIDED_THREADS), 0, s, a);
 }
