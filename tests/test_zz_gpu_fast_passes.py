@@ -1,0 +1,50 @@
+"""Detection passes of the per-cell FAST kernel on content chosen to reach each of its paths
+(core/lib/ORB/extractor.cc:789-807): cells that find corners at iniThFAST, cells that only find
+them at minThFAST (second pass), second-pass cells with more quick-test survivors than the
+queue holds (per-pixel path), and cells that find nothing at either threshold.  Candidates
+(order included), keypoints and descriptors must equal the oracle's."""
+import numpy as np
+import pytest
+
+import orb_slam3_amd as orbx
+
+pytestmark = pytest.mark.gpu
+
+
+def low_contrast_noise(w, h, amplitude, seed=3):
+    rng = np.random.default_rng(seed)
+    return (100 + rng.integers(0, amplitude + 1, (h, w))).astype(np.uint8)
+
+
+def mixed(w, h):
+    """Left third: strong texture; middle: faint noise (only the second pass fires); right: flat."""
+    img = np.full((h, w), 90, np.uint8)
+    img[:, : w // 3] = orbx.textured_frame(5, w, h)[:, : w // 3]
+    img[:, w // 3: 2 * w // 3] = low_contrast_noise(w, h, 16)[:, w // 3: 2 * w // 3]
+    return img
+
+
+@pytest.mark.parametrize("name,img,params", [
+    ("faint noise 16", low_contrast_noise(376, 240, 16), (500, 1.2, 4, 20, 7)),
+    ("faint noise 19", low_contrast_noise(376, 240, 19), (500, 1.2, 4, 20, 7)),
+    ("faint noise, thresholds 40/12", low_contrast_noise(376, 240, 30), (500, 1.2, 4, 40, 12)),
+    ("mixed", mixed(752, 480), (1000, 1.2, 8, 20, 7)),
+    ("equal thresholds", orbx.textured_frame(8, 376, 240), (400, 1.2, 4, 15, 15)),
+    ("ini below min", orbx.textured_frame(8, 376, 240), (400, 1.2, 4, 10, 25)),
+], ids=lambda v: v if isinstance(v, str) else None)
+def test_detection_paths_match_oracle(oracle, name, img, params):
+    ref = oracle.Extractor(*params)
+    st, rmono, rk, rd = ref.extract(img, (0, 0))
+    assert st == 0
+    ex = orbx.ORBextractor(*params)
+    mono, k, d = ex(img, None, (0, 0))
+    for l in range(params[2]):
+        assert np.array_equal(ex.debug_candidates(0, l), ref.candidates(l)), "%s: candidates level %d" % (name, l)
+    assert mono == rmono and len(k) == len(rk)
+    for fld in ("x", "y", "size", "response", "octave"):
+        assert np.array_equal(k[fld], rk[fld]), fld
+    if len(rk):
+        assert np.array_equal(d, rd)
+    if "faint" in name:
+        # nothing reaches iniThFAST, so every candidate comes from the second pass
+        assert len(rk) > 100 and rk["response"].max() < params[3]
