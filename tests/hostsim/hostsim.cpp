@@ -27,6 +27,31 @@
 #include <thread>
 #include <vector>
 
+// HOSTSIM_TSAN: the kernels are compiled with -fsanitize=thread and every simulated thread is a
+// fiber of its own to the race detector.  What orders two threads is told to it explicitly:
+// workgroup barriers, cross-lane operations of a wave, the start and the end of a workgroup.
+// Switching fibers orders nothing, so two threads that touch the same LDS or device memory
+// (one of them writing, not both atomically) with none of these in between are reported, however
+// the simulation happened to interleave them.  This file itself is built without
+// instrumentation: the scheduler's own state is not what is being checked.
+#ifdef HOSTSIM_TSAN
+extern "C" {
+void* __tsan_get_current_fiber(void);
+void* __tsan_create_fiber(unsigned flags);
+void __tsan_destroy_fiber(void* fiber);
+void __tsan_switch_to_fiber(void* fiber, unsigned flags);
+void __tsan_acquire(void* addr);
+void __tsan_release(void* addr);
+}
+#define TSAN_ACQUIRE(p) __tsan_acquire((void*)(p))
+#define TSAN_RELEASE(p) __tsan_release((void*)(p))
+#define TSAN_SWITCH(f) __tsan_switch_to_fiber((f), 1u /* no synchronisation */)
+#else
+#define TSAN_ACQUIRE(p) ((void)0)
+#define TSAN_RELEASE(p) ((void)0)
+#define TSAN_SWITCH(f) ((void)0)
+#endif
+
 namespace hostsim {
 
 static const size_t kPage = 4096;
@@ -76,6 +101,7 @@ struct Wave {
   int site = 0;
   uint64_t slot[2][64];
   uint64_t maskAt[2];
+  uint64_t order = 0;   // what the race detector's view of cross-lane operations hangs on
 };
 
 struct Block {
@@ -95,6 +121,11 @@ struct Block {
   Wave waves[kMaxThreads / 64];
   uint8_t* stacks = nullptr;     // kMaxThreads * kStack
   uint8_t* ldsRegion = nullptr;  // kLdsMax + guard
+  // race detector: one fiber per thread slot, kept for the life of this object (a slot's
+  // successive threads are ordered by that, which also covers their reuse of the slot's stack)
+  void* laneFiber[kMaxThreads] = {};
+  void* schedFiber = nullptr;
+  uint64_t orderStart = 0, orderBarrier = 0, orderDone = 0;
 };
 
 thread_local Lane* tl_lane = nullptr;
@@ -126,6 +157,7 @@ static void describe_position(FILE* f) {
 
 static inline void yield_to_scheduler() {
   Lane* l = tl_lane;
+  TSAN_SWITCH(tl_block->schedFiber);
   hostsim_switch(&l->sp, tl_block->schedSp);
 }
 
@@ -143,6 +175,7 @@ Gathered wave_gather(int site, uint64_t mine) {
   Wave& w = b->waves[l->lin >> 6];
   const int par = (int)(l->opCount++ & 1u);
   const int lane = l->lin & 63;
+  TSAN_RELEASE(&w.order);
   if (w.arrived == 0) w.site = site;
   else if (w.site != site) {
     fprintf(stderr, "hostsim: lanes of one wave meet at different cross-lane operations (lines %d and %d)\n",
@@ -159,12 +192,14 @@ Gathered wave_gather(int site, uint64_t mine) {
     l->site = site;
     wait_for(&w.gen, w.gen);
   }
+  TSAN_ACQUIRE(&w.order);
   return Gathered{w.slot[par], w.maskAt[par]};
 }
 
 static void barrier_impl(int site, int pred, int* orOut) {
   Block* b = tl_block;
   Lane* l = tl_lane;
+  TSAN_RELEASE(&b->orderBarrier);
   if (b->arrived == 0) b->site = site;
   else if (b->site != site) {
     fprintf(stderr, "hostsim: threads of one workgroup meet at different barriers (lines %d and %d)\n", b->site,
@@ -183,6 +218,7 @@ static void barrier_impl(int site, int pred, int* orOut) {
     l->site = site;
     wait_for(&b->gen, b->gen);
   }
+  TSAN_ACQUIRE(&b->orderBarrier);
   if (orOut) *orOut = b->orAcc[par];
 }
 
@@ -198,6 +234,11 @@ static void lane_exit() {
   Block* b = tl_block;
   Lane* l = tl_lane;
   Wave& w = b->waves[l->lin >> 6];
+  // a thread that has returned no longer takes part in barriers; what it wrote before is
+  // treated as visible to those who pass the next one
+  TSAN_RELEASE(&w.order);
+  TSAN_RELEASE(&b->orderBarrier);
+  TSAN_RELEASE(&b->orderDone);
   l->done = true;
   --w.alive;
   w.aliveMask &= ~(1ull << (l->lin & 63));
@@ -226,6 +267,7 @@ static void lane_exit() {
 }
 
 static void fiber_main() {
+  TSAN_ACQUIRE(&tl_block->orderStart);
   (*tl_block->fn)();
   lane_exit();
   for (;;) yield_to_scheduler();
@@ -315,6 +357,12 @@ static void run_block(Block* b, const char* name, uint3 bid, dim3 grid, dim3 blo
     prepare_fiber(b, i);
   }
   tl_block = b;
+#ifdef HOSTSIM_TSAN
+  b->schedFiber = __tsan_get_current_fiber();
+  for (int i = 0; i < nt; ++i)
+    if (!b->laneFiber[i]) b->laneFiber[i] = __tsan_create_fiber(0);
+#endif
+  TSAN_RELEASE(&b->orderStart);
   // HOSTSIM_ORDER=reverse runs the threads of a workgroup from the last to the first: code whose
   // result depends on which thread gets to a point first (a missing barrier) changes its output
   static const bool reverseOrder = [] { const char* e = getenv("HOSTSIM_ORDER"); return e && !strcmp(e, "reverse"); }();
@@ -326,6 +374,7 @@ static void run_block(Block* b, const char* name, uint3 bid, dim3 grid, dim3 blo
       if (l.done) continue;
       if (l.waitOn && *l.waitOn == l.waitVal) continue;
       tl_lane = &l;
+      TSAN_SWITCH(b->laneFiber[i]);
       hostsim_switch(&b->schedSp, l.sp);
       progressed = true;
     }
@@ -342,6 +391,7 @@ static void run_block(Block* b, const char* name, uint3 bid, dim3 grid, dim3 blo
     }
   }
   tl_lane = nullptr;
+  TSAN_ACQUIRE(&b->orderDone);
 }
 
 static int worker_count() {

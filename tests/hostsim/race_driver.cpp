@@ -1,0 +1,291 @@
+// Calls every entry point of the C ABI once on small inputs.  Built together with the kernels
+// under -fsanitize=thread (make race), it is what the race check runs: results are not compared
+// here (the parity tests do that), only reports of the race detector count.  Test
+// infrastructure only.
+#include <orbx.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <vector>
+
+#define CHECK(call)                                                                        \
+  do {                                                                                     \
+    const int st_ = (call);                                                                \
+    if (st_ != ORBX_OK) {                                                                  \
+      fprintf(stderr, "race_driver: %s -> %d (%s)\n", #call, st_, orbx_strerror(st_));     \
+      exit(2);                                                                             \
+    }                                                                                      \
+  } while (0)
+
+extern "C" {
+// HIP runtime subset of the simulation, for the calls that take device pointers
+int hipMalloc(void** p, size_t n);
+int hipFree(void* p);
+int hipMemcpy(void* d, const void* s, size_t n, int kind);
+}
+
+// content: "synth" = the textured bench frame; "noise" = uniform noise (far more candidates than
+// features wanted); "faint" = two gray values 19 apart (nothing at the first threshold, more
+// survivors of the quick test at the second than the detection kernel queues)
+static const char* g_content = "synth";
+static std::vector<uint8_t> synth(uint32_t seed, int w, int h) {
+  std::vector<uint8_t> img((size_t)w * h);
+  if (!strcmp(g_content, "synth")) {
+    CHECK(orbx_synth_frame(seed, w, h, w, img.data()));
+  } else {
+    std::mt19937 r(seed);
+    const bool faint = !strcmp(g_content, "faint");
+    for (auto& p : img) p = faint ? ((r() & 1) ? 100 : 119) : (uint8_t)r();
+  }
+  return img;
+}
+
+// a copy of descriptors with a few random bits flipped in each, so that nearest neighbours
+// are neither exact nor unique
+static std::vector<uint8_t> perturbed(const uint8_t* d, int n, int flips, std::mt19937& rng) {
+  std::vector<uint8_t> out(d, d + (size_t)n * 32);
+  for (int i = 0; i < n; ++i)
+    for (int f = 0; f < flips; ++f) {
+      const unsigned bit = rng() % 256;
+      out[(size_t)i * 32 + bit / 8] ^= (uint8_t)(1u << (bit % 8));
+    }
+  return out;
+}
+
+// right image of a rectified pair: the left one shifted by a few pixels
+static std::vector<uint8_t> shifted(const std::vector<uint8_t>& src, int w, int h, int d) {
+  std::vector<uint8_t> out((size_t)w * h);
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) out[(size_t)y * w + x] = src[(size_t)y * w + std::min(w - 1, x + d)];
+  return out;
+}
+
+static void step(const char* what) {
+  fprintf(stderr, "race_driver: %s\n", what);
+  fflush(stderr);
+}
+
+int main(int argc, char** argv) {
+  const int W = argc > 1 ? atoi(argv[1]) : 320, H = argc > 2 ? atoi(argv[2]) : 200;
+  const int nfeatures = argc > 3 ? atoi(argv[3]) : 400;
+  if (argc > 4) g_content = argv[4];
+  const int NF = 2;
+  std::mt19937 rng(7);
+
+  orbx_params prm;
+  prm.nfeatures = nfeatures;
+  prm.scale_factor = 1.2f;
+  prm.nlevels = 5;
+  prm.ini_th_fast = 20;
+  prm.min_th_fast = 7;
+  prm.device_id = 0;
+  prm.max_batch = NF;
+  orbx_extractor *left = nullptr, *right = nullptr;
+  CHECK(orbx_create(&prm, &left));
+  CHECK(orbx_create(&prm, &right));
+  const int cap = orbx_max_keypoints(left);
+
+  std::vector<std::vector<uint8_t>> imgsL, imgsR;
+  for (int f = 0; f < NF; ++f) {
+    imgsL.push_back(synth(0x0B5EEDu ^ (uint32_t)f, W, H));
+    imgsR.push_back(shifted(imgsL.back(), W, H, 6 + 3 * f));
+  }
+  const uint8_t* pl[NF] = {imgsL[0].data(), imgsL[1].data()};
+  const uint8_t* pr[NF] = {imgsR[0].data(), imgsR[1].data()};
+
+  std::vector<orbx_keypoint> kps((size_t)NF * cap), kpsR((size_t)NF * cap);
+  std::vector<uint8_t> desc((size_t)NF * cap * 32), descR((size_t)NF * cap * 32);
+  int n[NF], mono[NF], nR[NF], monoR[NF];
+
+  step("monocular extraction, single frame (keys fill the output back to front)");
+  {
+    int n1 = 0, m1 = 0;
+    CHECK(orbx_extract(left, pl[0], W, H, W, 0, 1000, kps.data(), desc.data(), cap, &n1, &m1));
+    const uint8_t* padded;
+    int lw, lh, ls;
+    CHECK(orbx_pyramid(left, 1, &padded, &lw, &lh, &ls));
+  }
+  step("extraction with a lapping area inside the image");
+  CHECK(orbx_extract_batch(left, NF, pl, W, H, W, W / 3, 2 * W / 3, kps.data(), desc.data(), cap, n, mono));
+  step("stereo pair extraction, batched");
+  CHECK(orbx_extract_batch(left, NF, pl, W, H, W, 0, 0, kps.data(), desc.data(), cap, n, mono));
+  CHECK(orbx_extract_batch(right, NF, pr, W, H, W, 0, 0, kpsR.data(), descR.data(), cap, nR, monoR));
+  fprintf(stderr, "race_driver: keypoints %d %d | %d %d\n", n[0], n[1], nR[0], nR[1]);
+
+  step("stereo association");
+  CHECK(orbx_stereo_match_batch_device(left, right, NF, 40.0f, 0.1f));
+  std::vector<float> uright(cap), depth(cap);
+  std::vector<int32_t> l1(cap);
+  int nn = 0;
+  for (int f = 0; f < NF; ++f) CHECK(orbx_stereo_download(left, f, uright.data(), depth.data(), l1.data(), cap, &nn));
+
+  step("row-band search on host arrays");
+  {
+    float scale[8];
+    CHECK(orbx_get_tables(left, scale, nullptr, nullptr, nullptr, nullptr));
+    std::vector<int32_t> bi(n[0]), bd(n[0]);
+    CHECK(orbx_stereo_band_match(0, kps.data(), desc.data(), n[0], kpsR.data(), descR.data(), nR[0], scale,
+                                 prm.nlevels, H, 0.0f, 40.0f, bi.data(), bd.data()));
+  }
+
+  step("frame grid, with and without distortion");
+  orbx_pinhole cam = {0.6f * W, 0.6f * W, 0.5f * W, 0.5f * H, -0.28f, 0.07f, 0.0002f, 0.00002f, 0.0f};
+  float bounds[4];
+  CHECK(orbx_image_bounds(&cam, W, H, bounds));
+  CHECK(orbx_frame_grid_batch_device(left, NF, &cam, bounds));
+  std::vector<orbx_keypoint> kun(cap);
+  std::vector<int32_t> cstart(64 * 48 + 1), centries(cap);
+  CHECK(orbx_frame_grid_download(left, 1, kun.data(), cstart.data(), centries.data(), cap, &nn));
+  CHECK(orbx_image_bounds(nullptr, W, H, bounds));
+  CHECK(orbx_frame_grid_batch_device(left, NF, nullptr, bounds));
+  CHECK(orbx_frame_grid_download(left, 0, kun.data(), cstart.data(), centries.data(), cap, &nn));
+
+  step("window queries on the grid");
+  {
+    const int nq = 300, pq = 64;
+    std::vector<float> q(5 * nq);
+    std::uniform_real_distribution<float> ux(-10.f, W + 10.f), uy(-10.f, H + 10.f), ur(2.f, 40.f);
+    for (int i = 0; i < nq; ++i) {
+      q[5 * i] = ux(rng);
+      q[5 * i + 1] = uy(rng);
+      q[5 * i + 2] = ur(rng);
+      q[5 * i + 3] = (float)((int)(rng() % 3) - 1);
+      q[5 * i + 4] = (i & 1) ? -1.0f : (float)(rng() % 5);
+    }
+    std::vector<int32_t> idx((size_t)nq * pq), cnt(nq);
+    CHECK(orbx_features_in_area(left, 0, q.data(), nq, idx.data(), pq, cnt.data()));
+  }
+
+  // "last frame" = frame 1 of the batch seen from frame 0: every keypoint of frame 0 projects
+  // near itself, so many of them compete for the same current keypoints
+  step("search by projection from the last frame");
+  {
+    const int nl = n[0];
+    std::vector<uint8_t> valid(nl), obs(nl), state(cap);
+    std::vector<float> uv(2 * (size_t)nl), invz(nl), ang(nl), ur(cap);
+    std::vector<int32_t> oct(nl), assigned(cap);
+    std::uniform_real_distribution<float> jitter(-4.f, 4.f);
+    for (int i = 0; i < nl; ++i) {
+      valid[i] = rng() % 8 != 0;
+      obs[i] = rng() % 4 != 0;
+      uv[2 * i] = kun[i].x + jitter(rng);
+      uv[2 * i + 1] = kun[i].y + jitter(rng);
+      invz[i] = 0.05f + 0.001f * (float)(rng() % 100);
+      ang[i] = kun[i].angle;
+      oct[i] = kun[i].octave;
+    }
+    for (int i = 0; i < cap; ++i) {
+      state[i] = (uint8_t)(rng() % 6 == 0 ? 1 + rng() % 2 : 0);
+      ur[i] = (rng() % 3 == 0) ? kun[i % std::max(1, nl)].x - 5.0f : -1.0f;
+    }
+    const std::vector<uint8_t> dl = perturbed(desc.data(), nl, 24, rng);
+    int nout = 0, nm = 0, rounds = 0;
+    for (int variant = 0; variant < 3; ++variant) {
+      CHECK(orbx_search_by_projection_last(left, 0, nl, valid.data(), uv.data(), invz.data(), oct.data(), ang.data(),
+                                           dl.data(), obs.data(), variant == 1 ? ur.data() : nullptr,
+                                           variant == 2 ? nullptr : state.data(), 15.0f, variant == 2, 0, 40.0f,
+                                           variant != 2, assigned.data(), cap, &nout, &nm, &rounds));
+      fprintf(stderr, "race_driver:   variant %d: %d matches in %d rounds\n", variant, nm, rounds);
+    }
+  }
+
+  step("search for initialization");
+  {
+    // F1 = the same keypoints with perturbed descriptors: neighbours compete for the same
+    // keypoint of F2
+    const int n1 = n[0];
+    std::vector<orbx_keypoint> k1(kun.begin(), kun.begin() + n1);
+    for (auto& kp : k1) kp.octave = 0;   // only level-0 keypoints of F1 take part (matcher.cc:642-645)
+    const std::vector<uint8_t> d1 = perturbed(desc.data(), n1, 40, rng);
+    std::vector<float> prev(2 * (size_t)n1);
+    std::uniform_real_distribution<float> jitter(-6.f, 6.f);
+    for (int i = 0; i < n1; ++i) {
+      prev[2 * i] = k1[i].x + jitter(rng);
+      prev[2 * i + 1] = k1[i].y + jitter(rng);
+    }
+    std::vector<int32_t> m12(n1);
+    int nm = 0, rounds = 0;
+    CHECK(orbx_search_for_initialization(left, 0, n1, k1.data(), d1.data(), prev.data(), 30,
+                                         0.9f, 1, m12.data(), &nm, &rounds));
+    fprintf(stderr, "race_driver:   %d matches in %d rounds\n", nm, rounds);
+  }
+
+  step("bag of words");
+  {
+    const int k = 6, L = 3;
+    std::vector<int32_t> parent;
+    std::vector<uint8_t> leaf, vd;
+    std::vector<double> wts;
+    std::vector<int> level = {0};
+    // complete k-ary tree in breadth-first order, random descriptors
+    for (size_t p = 0; p < level.size(); ++p) {
+      if (level[p] == L) continue;
+      for (int c = 0; c < k; ++c) {
+        parent.push_back((int32_t)p);
+        level.push_back(level[p] + 1);
+        leaf.push_back(level[p] + 1 == L);
+        for (int b = 0; b < 32; ++b) vd.push_back((uint8_t)rng());
+        wts.push_back(level[p] + 1 == L ? 0.1 + (double)(rng() % 1000) / 500.0 : 0.0);
+      }
+    }
+    orbx_vocabulary* voc = nullptr;
+    CHECK(orbx_vocabulary_create(k, L, 0, 0, (int)parent.size(), parent.data(), leaf.data(), vd.data(), wts.data(),
+                                 0, &voc));
+    for (int levelsup : {4, 1, 0}) {
+      CHECK(orbx_bow_transform_batch_device(left, voc, NF, levelsup));
+      std::vector<uint32_t> wid(cap), nid(cap), feats(cap);
+      std::vector<double> wv(cap);
+      std::vector<int32_t> nstart(cap + 1);
+      int nw = 0, nnodes = 0;
+      for (int f = 0; f < NF; ++f)
+        CHECK(orbx_bow_download(left, f, wid.data(), wv.data(), &nw, nid.data(), nstart.data(), feats.data(),
+                                &nnodes, cap));
+    }
+    orbx_vocabulary_destroy(voc);
+  }
+
+  step("brute-force 2-NN and the merge of partial results");
+  {
+    const int nq = 300;
+    const int64_t nt = 1500;
+    std::vector<uint8_t> q((size_t)nq * 32), t((size_t)nt * 32);
+    for (auto& b : q) b = (uint8_t)rng();
+    for (auto& b : t) b = (uint8_t)rng();
+    std::vector<uint32_t> idx(2 * (size_t)nq);
+    std::vector<uint16_t> dist(2 * (size_t)nq);
+    CHECK(orbx_knn2(0, q.data(), nq, t.data(), nt, idx.data(), dist.data()));
+    CHECK(orbx_knn2(0, q.data(), 3, t.data(), 1, idx.data(), dist.data()));
+    // two shards on device pointers + merge
+    void *dq, *dt, *di, *dd, *dio, *ddo;
+    hipMalloc(&dq, q.size());
+    hipMalloc(&dt, t.size());
+    hipMalloc(&di, 2 * 2 * (size_t)nq * 4);
+    hipMalloc(&dd, 2 * 2 * (size_t)nq * 2);
+    hipMalloc(&dio, 2 * (size_t)nq * 4);
+    hipMalloc(&ddo, 2 * (size_t)nq * 2);
+    hipMemcpy(dq, q.data(), q.size(), 1);
+    hipMemcpy(dt, t.data(), t.size(), 1);
+    const int64_t half = nt / 2;
+    CHECK(orbx_knn2_device((const uint8_t*)dq, nq, (const uint8_t*)dt, half, 0, (uint32_t*)di, (uint16_t*)dd, nullptr));
+    CHECK(orbx_knn2_device((const uint8_t*)dq, nq, (const uint8_t*)dt + half * 32, nt - half, (uint32_t)half,
+                           (uint32_t*)di + 2 * nq, (uint16_t*)dd + 2 * nq, nullptr));
+    CHECK(orbx_top2_merge_device((const uint32_t*)di, (const uint16_t*)dd, 2, nq, (uint32_t*)dio, (uint16_t*)ddo,
+                                 nullptr));
+    hipFree(dq); hipFree(dt); hipFree(di); hipFree(dd); hipFree(dio); hipFree(ddo);
+  }
+
+  step("sort hook");
+  {
+    std::vector<uint64_t> rec(777);
+    for (auto& r : rec) r = ((uint64_t)(rng() % 40) << 32) | (uint32_t)rng();
+    CHECK(orbx_debug_sort_records(0, rec.data(), (int)rec.size()));
+  }
+
+  orbx_destroy(left);
+  orbx_destroy(right);
+  step("done");
+  return 0;
+}
