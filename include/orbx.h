@@ -25,7 +25,8 @@ extern "C" {
 typedef enum orbx_status {
   ORBX_OK = 0,
   ORBX_ERR_EMPTY_IMAGE = -1,  /* reference returns -1, core/lib/ORB/extractor.cc:1023-1024 */
-  ORBX_ERR_TOO_SMALL = -2,    /* a pyramid level has no 35-px cell (reference: undefined) */
+  ORBX_ERR_TOO_SMALL = -2,    /* a pyramid level has no 35-px cell, or is so much taller than
+                               * wide that extractor.cc:549 rounds nIni to 0 (reference: undefined) */
   ORBX_ERR_CAPACITY = -3,     /* output capacity too small; *n_out holds the need */
   ORBX_ERR_BAD_ARG = -4,
   ORBX_ERR_NO_DEVICE = -5,    /* no usable HIP device / HIP runtime error at set-up */

@@ -598,7 +598,7 @@ const char* orbx_strerror(int status) {
   switch (status) {
     case ORBX_OK: return "ok";
     case ORBX_ERR_EMPTY_IMAGE: return "empty image";
-    case ORBX_ERR_TOO_SMALL: return "image too small: a pyramid level has no 35-pixel detection cell";
+    case ORBX_ERR_TOO_SMALL: return "image too small: a pyramid level has no 35-pixel detection cell (or no quadtree root: much taller than wide)";
     case ORBX_ERR_CAPACITY: return "output capacity too small";
     case ORBX_ERR_BAD_ARG: return "bad argument";
     case ORBX_ERR_NO_DEVICE: return "no usable HIP device";

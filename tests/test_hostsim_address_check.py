@@ -31,3 +31,15 @@ def test_gpu_suite_under_host_simulation(guard, order):
     tail = (out.stdout + out.stderr)[-3000:]
     assert out.returncode == 0, tail
     assert " passed" in out.stdout and " failed" not in out.stdout, tail
+
+
+def test_random_configurations_under_host_simulation():
+    """tools/fuzz_parity.py draws image sizes, contents, extractor parameters and matcher inputs
+    and compares every stage with the oracle; a short fixed range of its cases runs here (longer
+    ranges are run by hand: 1600 cases passed when this was written)."""
+    env = dict(os.environ, ORBX_HOSTSIM="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "--cases", "40", "--start",
+                          "5000"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    tail = (out.stdout + out.stderr)[-3000:]
+    assert out.returncode == 0, tail
+    assert "40 cases, 0 failures" in out.stdout, tail
