@@ -4,7 +4,8 @@
 Every case draws an image size, content, extractor parameters, thresholds and a lapping area,
 compares the extraction stage by stage (pyramid bytes, candidates, quadtree selections, blurred
 bytes, keypoints, descriptors), then the stereo association, the frame grid with window queries,
-both guided matchers and the bag-of-words transform on what was extracted - all bit-exact except
+both guided matchers and the bag-of-words transform on what was extracted, and a brute-force 2-NN
+on random descriptor sets - all bit-exact except
 the angle (1e-4 rad).  On a GPU box it runs the real library; with ORBX_HOSTSIM=1 and no GPU it
 runs the kernels under tests/hostsim (guarded memory), which is how it is used where there is no
 device.  The case number is the seed: `--only N` repeats one case.
@@ -106,7 +107,9 @@ def both_refuse(img, params, lap):
     except orbx.OrbxError as e:
         got = e.status
     h, w = img.shape
-    if got == -7 and st == 0 and (w - 32) / (h - 32) > 16.4:
+    sf, nl = params[1], params[2]
+    widest = max((round(w / sf ** l) - 32) / (round(h / sf ** l) - 32) for l in range(nl))
+    if got == -7 and st == 0 and widest > 16.4:
         return "refused by the library as unsupported (more than 16 quadtree roots)"
     assert got == st, "status %d, oracle %d" % (got, st)
     return "refused by both (status %d)" % st if st else None
@@ -224,6 +227,19 @@ def grid_and_matchers(rng, img, params):
     return "proj %d in %d rounds, init %d in %d rounds, %d words" % (n, rounds, n2, rounds2, len(wi))
 
 
+def knn_part(rng):
+    """Brute-force 2-NN on random sizes; a small pool of distinct rows makes distance ties the rule."""
+    nq, nt = int(rng.integers(1, 1300)), int(rng.choice([0, 1, 2, int(rng.integers(3, 6000))], p=[.03, .03, .04, .9]))
+    pool = rng.integers(0, 256, (int(rng.choice([3, 40, 100000])), 32), dtype=np.uint8)
+    t = pool[rng.integers(0, len(pool), nt)] if len(pool) < 100000 else rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+    q = pool[rng.integers(0, len(pool), nq)].copy() if len(pool) < 100000 else rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+    q[:, int(rng.integers(0, 32))] ^= rng.integers(0, 4, nq).astype(np.uint8)
+    idx, dist = orbx.knn_match2(q, np.ascontiguousarray(t))
+    ridx, rdist = oracle.knn2(q, np.ascontiguousarray(t))
+    assert np.array_equal(dist, rdist) and np.array_equal(idx, ridx), "2-NN %d x %d" % (nq, nt)
+    return "2-NN %dx%d" % (nq, nt)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=50)
@@ -239,6 +255,7 @@ def main():
         t0 = time.time()
         head = "case %d: %dx%d %s params %s lap %s" % (seed, w, h, kind, params, lap)
         try:
+            knn = knn_part(rng)
             img = content(rng, kind, w, h)
             refused = both_refuse(img, params, lap)
             if refused:
@@ -248,7 +265,8 @@ def main():
             msg = "%d descriptor rows differ" % bad if bad else "extraction equal"
             nstereo = stereo_part(rng, img, params)
             rest = grid_and_matchers(rng, img, params)
-            print("%s: %s, %d stereo matches, %s (%.1f s)" % (head, msg, nstereo, rest, time.time() - t0), flush=True)
+            print("%s: %s, %d stereo matches, %s, %s (%.1f s)" % (head, msg, nstereo, rest, knn, time.time() - t0),
+                  flush=True)
         except Exception:
             failures += 1
             print("%s: FAILED" % head, flush=True)
