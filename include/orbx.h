@@ -306,7 +306,8 @@ int orbx_search_for_initialization(orbx_extractor* f2, int frame2, int n1, const
 /* ---- bag of words ------------------------------------------------------------ */
 /* The reference's ORBVocabulary (core/lib/ORB/vocabulary.h:31-62) in device
  * memory.  Supported: TF_IDF (0) or TF (1) weighting with L1 scoring (0), the
- * stock configuration; other combinations return ORBX_ERR_UNSUPPORTED. */
+ * stock configuration; other combinations return ORBX_ERR_UNSUPPORTED.  Under
+ * both modes a word counts with the weight its node stores (the file's). */
 typedef struct orbx_vocabulary orbx_vocabulary;
 /* ORBVocabulary::loadFromText, core/lib/ORB/vocabulary.cc:96-160: first line
  * "k L scoring weighting", then one node per line "parent isLeaf d0 .. d31

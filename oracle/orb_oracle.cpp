@@ -1302,7 +1302,9 @@ int orc_bow_transform(void* h, const uint8_t* desc, int n, int levelsup, uint32_
       if (current_level == nid_level) nid = (unsigned)final_id;
     } while (!v->nodes[final_id].children.empty());
     const unsigned word = v->nodes[final_id].word_id;
-    const double w = v->weighting == 1 ? 1.0 : v->nodes[final_id].weight;   // TF: weight 1
+    // the stored weight under TF as under TF_IDF: the descent returns Node::weight and the
+    // weighting mode only decides how weights are computed when a vocabulary is trained
+    const double w = v->nodes[final_id].weight;
     if (w > 0) {
       auto it = bow.lower_bound(word);
       if (it != bow.end() && !(bow.key_comp()(word, it->first))) it->second += w;

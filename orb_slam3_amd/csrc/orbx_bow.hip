@@ -68,7 +68,9 @@ __global__ __launch_bounds__(BOW_THREADS) void k_bow_descend(VocDevice voc, cons
   if (j == 0) {
     const size_t o = (size_t)f * cap + i;
     featWord[o] = voc.nodeWord[node];
-    featWeight[o] = voc.weighting == 1 ? 1.0 : voc.nodeWeight[node];   // TF: every word weighs 1
+    // the stored Node::weight under TF_IDF and TF alike (a vocabulary built with TF stores 1
+    // in every word, but a file may say otherwise and transform() does not look at the mode)
+    featWeight[o] = voc.nodeWeight[node];
     featNode[o] = nid;
   }
 }
@@ -290,7 +292,11 @@ extern "C" {
 int orbx_vocabulary_create(int k, int L, int scoring, int weighting, int n_nodes, const int32_t* parent,
                            const uint8_t* is_leaf, const uint8_t* descriptors, const double* weights,
                            int device_id, orbx_vocabulary** out) {
-  return build_vocabulary(k, L, scoring, weighting, n_nodes, parent, is_leaf, descriptors, weights, device_id, out);
+  try {
+    return build_vocabulary(k, L, scoring, weighting, n_nodes, parent, is_leaf, descriptors, weights, device_id, out);
+  } catch (...) {   // host allocation failure: no exception leaves the C ABI
+    return ORBX_ERR_UNSUPPORTED;
+  }
 }
 
 int orbx_vocabulary_load_text(const char* path, int device_id, orbx_vocabulary** out) {
@@ -298,6 +304,7 @@ int orbx_vocabulary_load_text(const char* path, int device_id, orbx_vocabulary**
   *out = nullptr;
   FILE* f = std::fopen(path, "r");
   if (!f) return ORBX_ERR_BAD_ARG;
+  try {
   int k = 0, L = 0, n1 = 0, n2 = 0;
   // header checks of vocabulary.cc:111-117
   if (std::fscanf(f, "%d %d %d %d", &k, &L, &n1, &n2) != 4 || k < 0 || k > 20 || L < 1 || L > 10 || n1 < 0 ||
@@ -325,9 +332,14 @@ int orbx_vocabulary_load_text(const char* path, int device_id, orbx_vocabulary**
     weight.push_back(w);
   }
   std::fclose(f);
+  f = nullptr;
   if (!ok) return ORBX_ERR_BAD_ARG;
   return build_vocabulary(k, L, n1, n2, (int)parent.size(), parent.data(), leaf.data(), desc.data(), weight.data(),
                           device_id, out);
+  } catch (...) {   // host allocation failure: no exception leaves the C ABI
+    if (f) std::fclose(f);
+    return ORBX_ERR_UNSUPPORTED;
+  }
 }
 
 void orbx_vocabulary_destroy(orbx_vocabulary* v) {

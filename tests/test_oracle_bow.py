@@ -66,7 +66,7 @@ def _numpy_transform(k, L, arrays, feats, levelsup, weighting=0):
             node = ch[int(np.argmin(d))]
             if level == L - levelsup:
                 nid = node
-        wt = 1.0 if weighting == 1 else weight[node - 1]
+        wt = weight[node - 1]          # the stored weight, whatever the weighting mode
         if wt > 0:
             bow[word[node]] = bow.get(word[node], 0.0) + wt if word[node] in bow else wt
             fv.setdefault(nid, []).append(fi)
