@@ -186,6 +186,7 @@ struct orbx_extractor {
 
   void buildTables();
   int ensurePlan(int W, int H);
+  int buildPlan(int W, int H);
   void freePlan();
   int run(const uint8_t* d_images, int istride, size_t iframe, int nframes, int lap0, int lap1);
 };
@@ -282,7 +283,16 @@ static void build_taps(int sn, int dn, bool horizontal, std::vector<Tap>& out) {
   for (int p = 0; p < dn + 2 * ORBX_EDGE; ++p) out[p] = t[reflect101(p - ORBX_EDGE, dn)];
 }
 
+// buildPlan with the C ABI's promise kept: a failed host allocation becomes a status
 int orbx_extractor::ensurePlan(int W, int H) {
+  try {
+    return buildPlan(W, H);
+  } catch (...) {
+    return ORBX_ERR_UNSUPPORTED;
+  }
+}
+
+int orbx_extractor::buildPlan(int W, int H) {
   if (planned && hp.W == W && hp.H == H) return ORBX_OK;
   freePlan();
   const int nl = prm.nlevels;
@@ -622,7 +632,12 @@ int orbx_create(const orbx_params* p, orbx_extractor** out) {
   if (!ex) return ORBX_ERR_BAD_ARG;
   ex->prm = *p;
   ex->device = p->device_id;
-  ex->buildTables();
+  try {
+    ex->buildTables();
+  } catch (...) {
+    delete ex;
+    return ORBX_ERR_UNSUPPORTED;
+  }
   if (hipSetDevice(ex->device) != hipSuccess ||
       hipStreamCreateWithFlags(&ex->stream, hipStreamNonBlocking) != hipSuccess) {
     delete ex;
