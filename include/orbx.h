@@ -292,6 +292,24 @@ int orbx_search_by_projection_last(orbx_extractor* cur, int frame, int n_last, c
                                    const uint8_t* last_obs, const float* u_right, const uint8_t* state,
                                    float th, int forward, int backward, float mbf, int check_orientation,
                                    int32_t* assigned, int cap, int* n_out, int* nmatches, int* rounds);
+/* ORBmatcher::SearchByProjection(F, vpMapPoints, th, bFarPoints, thFarPoints),
+ * core/lib/ORB/matcher.cc:41-142, monocular / rectified case (Nleft == -1): the
+ * local-map matcher of Tracking::SearchLocalPoints.  F is frame `frame` of the
+ * last extraction + grid call on `f`.  The map points arrive as flat host
+ * arrays holding what Frame::isInFrustum left in them:
+ *   in_view[i]   mbTrackInView, not bad, not beyond thFarPoints (:51-60)
+ *   proj[2i], proj[2i+1]  mTrackProjX, mTrackProjY;  proj_xr[i]  mTrackProjXR
+ *   level[i]     mnTrackScaleLevel;  view_cos[i]  mTrackViewCos (:64, :215-220)
+ *   desc         the map point's descriptor, 32 bytes each
+ *   obs[i]       pMP->Observations() > 0 (what :89-91 finds once it is assigned)
+ * u_right, state, assigned, cap, n_out, rounds as in
+ * orbx_search_by_projection_last (no rotation check here, so no -2).  nnratio
+ * is the matcher's constructor argument.  *nmatches = the return value. */
+int orbx_search_by_projection_points(orbx_extractor* f, int frame, int n_points, const uint8_t* in_view,
+                                     const float* proj, const float* proj_xr, const int32_t* level,
+                                     const float* view_cos, const uint8_t* desc, const uint8_t* obs,
+                                     const float* u_right, const uint8_t* state, float th, float nnratio,
+                                     int32_t* assigned, int cap, int* n_out, int* nmatches, int* rounds);
 /* ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12,
  * windowSize), core/lib/ORB/matcher.cc:629-733.  F2 is frame `frame2` of the
  * last extraction + grid call on `f2`; F1 arrives as host arrays (mvKeysUn and

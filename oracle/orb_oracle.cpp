@@ -1175,6 +1175,70 @@ int orc_search_by_projection_last(const uint8_t* lastValid, const float* uv, con
   return nmatches;
 }
 
+// ORBmatcher::SearchByProjection(F, vpMapPoints, th, bFarPoints, thFarPoints), core/lib/ORB/
+// matcher.cc:41-213, for a monocular or rectified frame (Nleft == -1; the right-camera half,
+// :144-210, only runs for fisheye pairs), on flat arrays.  What Frame::isInFrustum left in every
+// map point is the caller's:
+//   inView[i]    mbTrackInView, not bad, and not beyond thFarPoints when bFarPoints (:51-60)
+//   proj[2i..]   mTrackProjX, mTrackProjY;  projXR[i]  mTrackProjXR
+//   level[i]     mnTrackScaleLevel;  viewCos[i]  mTrackViewCos
+//   ptDesc       the map point's descriptor, 32 bytes each
+//   ptObs[i]     pMP->Observations() > 0, consulted when a later map point meets this match (:89-91)
+// Frame: as in orc_search_by_projection_last.  assigned[i2] = index of the map point keypoint i2
+// received (-1 untouched).  Returns nmatches (every assignment counts, :137).
+int orc_search_by_projection_points(const uint8_t* inView, const float* proj, const float* projXR,
+                                    const int* level, const float* viewCos, const uint8_t* ptDesc,
+                                    const uint8_t* ptObs, int nPts, const void* kpsUn28, const uint8_t* desc,
+                                    const float* uRight, const uint8_t* state, int n, const float* bounds,
+                                    const int* cellStart, const int* entries, const float* scaleFactors,
+                                    float th, float nnratio, int* assigned) {
+  const KeyPoint* K = (const KeyPoint*)kpsUn28;
+  const int TH_HIGH = 100;
+  int nmatches = 0;
+  for (int i = 0; i < n; ++i) assigned[i] = -1;
+  std::vector<uint8_t> blocked(std::max(n, 1));
+  for (int i = 0; i < n; ++i) blocked[i] = state[i] == 1;
+  std::vector<int> idx(std::max(n, 1));
+  const bool bFactor = th != 1.0;
+  for (int iMP = 0; iMP < nPts; ++iMP) {
+    if (!inView[iMP]) continue;
+    const int nPredictedLevel = level[iMP];
+    float r = viewCos[iMP] > 0.998 ? 2.5f : 4.0f;   // RadiusByViewingCos, :215-220 (compared as double)
+    if (bFactor) r *= th;
+    const float radius = r * scaleFactors[nPredictedLevel];
+    const int found = orc_features_in_area(bounds, kpsUn28, cellStart, entries, proj[2 * iMP], proj[2 * iMP + 1],
+                                           radius, nPredictedLevel - 1, nPredictedLevel, idx.data(), n);
+    if (found == 0) continue;
+    int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+    for (int c = 0; c < found; ++c) {
+      const int i2 = idx[c];
+      if (blocked[i2]) continue;
+      if (uRight && uRight[i2] > 0) {
+        const float er = std::fabs(projXR[iMP] - uRight[i2]);
+        if (er > radius) continue;
+      }
+      const int dist = hamming256(ptDesc + (size_t)iMP * 32, desc + (size_t)i2 * 32);
+      if (dist < bestDist) {
+        bestDist2 = bestDist; bestDist = dist;
+        bestLevel2 = bestLevel; bestLevel = K[i2].octave;
+        bestIdx = i2;
+      } else if (dist < bestDist2) {
+        bestLevel2 = K[i2].octave;
+        bestDist2 = dist;
+      }
+    }
+    if (bestDist <= TH_HIGH) {
+      if (bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) continue;
+      if (bestLevel != bestLevel2 || (float)bestDist <= nnratio * (float)bestDist2) {
+        assigned[bestIdx] = iMP;
+        blocked[bestIdx] = ptObs[iMP] != 0;
+        nmatches++;
+      }
+    }
+  }
+  return nmatches;
+}
+
 }  // extern "C"
 
 // ---- bag of words (Frame::ComputeBoW, core/src/Frame.cc:764-769) -----------------------------

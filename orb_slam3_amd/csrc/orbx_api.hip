@@ -62,6 +62,13 @@ void launch_search_for_initialization(const float* d_kps1Un, const uint8_t* d_de
                                       const int* d_cellStart2, const int* d_entries2, const float* bounds2,
                                       float window, float nnratio, int checkOrientation, int* d_work,
                                       int* d_matches12, int* d_summary, hipStream_t s);
+void launch_search_by_projection_points(const uint8_t* d_inView, const float* d_proj, const float* d_projXR,
+                                        const int* d_level, const float* d_viewCos, const uint8_t* d_ptDesc,
+                                        const uint8_t* d_ptObs, int nPts, const float* d_kpsUn, const uint8_t* d_desc,
+                                        const float* d_uRight, const uint8_t* d_state, int n, const int* d_cellStart,
+                                        const int* d_entries, const float* bounds, const float* scaleFactors,
+                                        int nlevels, float th, float nnratio, int* d_work, int* d_assigned,
+                                        int* d_summary, hipStream_t s);
 }  // namespace orbx
 
 using orbx::LevelDesc;
@@ -1083,6 +1090,71 @@ int orbx_search_by_projection_last(orbx_extractor* cur, int frame, int n_last, c
         ex->d_cellStart + (size_t)frame * (ORBX_GRID_CELLS + 1), ex->d_cellEntries + base, ex->gridBounds,
         ex->scale.data(), ex->prm.nlevels, th, forward != 0, backward != 0, mbf, check_orientation != 0,
         (int*)(d + oWork), (int*)(d + oAsg), (int*)(d + oSum), s);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(assigned, d + oAsg, nn * 4, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(sum, d + oSum, 8, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFreeAsync(d, s);
+  if (e != hipSuccess) { last_hip_error = e; return ORBX_ERR_HIP; }
+  *nmatches = sum[0];
+  if (rounds) *rounds = sum[1];
+  return ORBX_OK;
+}
+
+int orbx_search_by_projection_points(orbx_extractor* f, int frame, int n_points, const uint8_t* in_view,
+                                     const float* proj, const float* proj_xr, const int32_t* level,
+                                     const float* view_cos, const uint8_t* desc, const uint8_t* obs,
+                                     const float* u_right, const uint8_t* state, float th, float nnratio,
+                                     int32_t* assigned, int cap, int* n_out, int* nmatches, int* rounds) {
+  orbx_extractor* ex = f;
+  if (!ex || !ex->planned || !ex->d_kpsUn || frame < 0 || frame >= ex->gridFrames || n_points < 0 ||
+      n_points > kGuidedMaxQueries || cap < 0 || !nmatches)
+    return ORBX_ERR_BAD_ARG;
+  if (n_points > 0 && (!in_view || !proj || !proj_xr || !level || !view_cos || !desc || !obs)) return ORBX_ERR_BAD_ARG;
+  for (int i = 0; i < n_points; ++i)
+    if (in_view[i] && (level[i] < 0 || level[i] >= ex->prm.nlevels)) return ORBX_ERR_BAD_ARG;
+  if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  auto& last_hip_error = ex->last_hip_error;
+  hipStream_t s = ex->stream;
+  int n = 0;
+  HIP_TRY(hipMemcpyAsync(&n, ex->d_n + frame, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (n_out) *n_out = n;
+  *nmatches = 0;
+  if (rounds) *rounds = 0;
+  if (n > cap) return ORBX_ERR_CAPACITY;
+  if (n > 0 && !assigned) return ORBX_ERR_BAD_ARG;
+  if (n == 0) return ORBX_OK;
+  if (n_points == 0) {
+    for (int i = 0; i < n; ++i) assigned[i] = -1;
+    return ORBX_OK;
+  }
+  const size_t np = (size_t)n_points, nn = (size_t)n;
+  Carver c;
+  const size_t oView = c.add(np), oProj = c.add(np * 8), oXr = c.add(np * 4), oLvl = c.add(np * 4),
+               oCos = c.add(np * 4), oDesc = c.add(np * 32), oObs = c.add(np), oUr = c.add(nn * 4),
+               oState = c.add(nn), oWork = c.add(orbx::projection_work_ints(n_points, n) * 4),
+               oAsg = c.add(nn * 4), oSum = c.add(8);
+  uint8_t* d = nullptr;
+  hipError_t e = hipMallocAsync((void**)&d, c.total, s);
+  if (e != hipSuccess) { last_hip_error = e; return ORBX_ERR_HIP; }
+  auto up = [&](size_t off, const void* src, size_t bytes) {
+    if (e == hipSuccess) e = hipMemcpyAsync(d + off, src, bytes, hipMemcpyHostToDevice, s);
+  };
+  up(oView, in_view, np); up(oProj, proj, np * 8); up(oXr, proj_xr, np * 4); up(oLvl, level, np * 4);
+  up(oCos, view_cos, np * 4); up(oDesc, desc, np * 32); up(oObs, obs, np);
+  if (u_right) up(oUr, u_right, nn * 4);
+  if (state) up(oState, state, nn);
+  int sum[2] = {0, 0};
+  if (e == hipSuccess) {
+    const size_t base = (size_t)frame * ex->hp.kp_cap;
+    orbx::launch_search_by_projection_points(
+        d + oView, (const float*)(d + oProj), (const float*)(d + oXr), (const int*)(d + oLvl),
+        (const float*)(d + oCos), d + oDesc, d + oObs, n_points, ex->d_kpsUn + base * 7, ex->d_desc + base * 32,
+        u_right ? (const float*)(d + oUr) : nullptr, state ? d + oState : nullptr, n,
+        ex->d_cellStart + (size_t)frame * (ORBX_GRID_CELLS + 1), ex->d_cellEntries + base, ex->gridBounds,
+        ex->scale.data(), ex->prm.nlevels, th, nnratio, (int*)(d + oWork), (int*)(d + oAsg), (int*)(d + oSum), s);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipMemcpyAsync(assigned, d + oAsg, nn * 4, hipMemcpyDeviceToHost, s);

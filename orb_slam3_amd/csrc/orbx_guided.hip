@@ -2,6 +2,8 @@
 // 64 x 48 frame grid of orbx_grid.hip):
 //   k_search_by_projection_last   ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono)
 //                                 core/lib/ORB/matcher.cc:1591-1808 (monocular / rectified case)
+//   k_search_by_projection_points ORBmatcher::SearchByProjection(F, vpMapPoints, th, ...)
+//                                 matcher.cc:41-142 (the local-map matcher; same case)
 //   k_search_for_initialization   ORBmatcher::SearchForInitialization   matcher.cc:629-733
 //   three_maxima                  ORBmatcher::ComputeThreeMaxima        matcher.cc:1925-1957
 //
@@ -291,6 +293,158 @@ __global__ __launch_bounds__(GUIDED_THREADS) void k_search_by_projection_last(Pr
   if (tid == 0) { a.summary[0] = nmS; a.summary[1] = rounds; }
 }
 
+struct PointsArgs {
+  // map points, one entry each: what Frame::isInFrustum left in them (matcher.cc:51-72, 94)
+  const uint8_t* inView;
+  const float* proj;       // mTrackProjX, mTrackProjY
+  const float* projXR;     // mTrackProjXR
+  const int* level;        // mnTrackScaleLevel
+  const float* viewCos;    // mTrackViewCos
+  const uint32_t* ptDesc;
+  const uint8_t* ptObs;
+  int nPts;
+  // frame
+  GridView grid;
+  const uint32_t* desc;
+  const float* uRight;     // may be null: monocular
+  const uint8_t* state;    // may be null: every keypoint free
+  int n;
+  float scale[ORBX_MAX_LEVELS];
+  float th, nnratio;
+  // work arrays, as in ProjectionArgs
+  int* choice[2];
+  int* closedAt[2];
+  uint32_t* cand;          // distance << 20 | octave << 16 | keypoint
+  int* candCount;
+  // results
+  int* assigned;           // n
+  int* summary;            // [0] nmatches, [1] rounds
+};
+
+// best and second-best candidate with their pyramid levels, and the acceptance rule of
+// matcher.cc:77-127: the ratio test only applies when both come from the same level
+struct BestTwo {
+  int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+  __device__ __forceinline__ void consider(int i2, int dist, int octave) {
+    if (dist < bestDist) {
+      bestDist2 = bestDist; bestDist = dist;
+      bestLevel2 = bestLevel; bestLevel = octave;
+      bestIdx = i2;
+    } else if (dist < bestDist2) {
+      bestLevel2 = octave;
+      bestDist2 = dist;
+    }
+  }
+  __device__ __forceinline__ int accepted(float nnratio) const {
+    if (bestDist > TH_HIGH) return -1;
+    if (bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(nnratio, (float)bestDist2)) return -1;
+    return bestIdx;
+  }
+};
+
+// choice of map point i given the closing times of the previous round.  store: remember the
+// candidates.
+__device__ int points_choice(const PointsArgs& a, int i, const int* closedAt, bool store) {
+  if (store) a.candCount[i] = 0;
+  if (!a.inView[i]) return -1;
+  const int nPredictedLevel = a.level[i];
+  // RadiusByViewingCos (matcher.cc:215-220; the comparison is made in double)
+  float r = (double)a.viewCos[i] > 0.998 ? 2.5f : 4.0f;
+  if ((double)a.th != 1.0) r = __fmul_rn(r, a.th);
+  const float radius = __fmul_rn(r, a.scale[nPredictedLevel]);
+  uint32_t dMP[8];
+#pragma unroll
+  for (int w = 0; w < 8; ++w) dMP[w] = a.ptDesc[(size_t)i * 8 + w];
+  const float xr = a.projXR[i];
+  BestTwo b;
+  int k = 0;
+  for_each_in_area(a.grid, a.proj[2 * i], a.proj[2 * i + 1], radius, nPredictedLevel - 1, nPredictedLevel, [&](int i2) {
+    if (a.uRight) {
+      const float r2 = a.uRight[i2];
+      if (r2 > 0) {
+        const float er = fabsf(__fsub_rn(xr, r2));
+        if (er > radius) return;
+      }
+    }
+    const int dist = hamming_reg(dMP, a.desc + (size_t)i2 * 8);
+    const int octave = a.grid.U[i2].octave;
+    if (store) {
+      if (k < GUIDED_CACHE)
+        a.cand[(size_t)k * a.nPts + i] = ((uint32_t)dist << 20) | ((uint32_t)octave << 16) | (uint32_t)i2;
+      ++k;
+    }
+    if (coherent_load(&closedAt[i2]) < i) return;   // holds a map point with observations (:89-91)
+    b.consider(i2, dist, octave);
+  });
+  if (store) a.candCount[i] = k <= GUIDED_CACHE ? k : -1;
+  return b.accepted(a.nnratio);
+}
+
+__device__ int points_choice_cached(const PointsArgs& a, int i, const int* closedAt, int cnt) {
+  BestTwo b;
+  for (int k = 0; k < cnt; ++k) {
+    const uint32_t e = a.cand[(size_t)k * a.nPts + i];
+    const int i2 = (int)(e & 0xFFFFu);
+    if (coherent_load(&closedAt[i2]) < i) continue;
+    b.consider(i2, (int)(e >> 20), (int)((e >> 16) & 0xFu));
+  }
+  return b.accepted(a.nnratio);
+}
+
+__global__ __launch_bounds__(GUIDED_THREADS) void k_search_by_projection_points(PointsArgs a) {
+  __shared__ int nmS;
+  const int tid = threadIdx.x;
+  const int OPEN = 0x7fffffff;
+  for (int i = tid; i < a.nPts; i += GUIDED_THREADS) a.choice[0][i] = -1;
+  for (int i2 = tid; i2 < a.n; i2 += GUIDED_THREADS)
+    a.closedAt[0][i2] = (a.state && a.state[i2] == 1) ? -1 : OPEN;
+  if (tid == 0) nmS = 0;
+  __syncthreads();
+  int cur = 0, rounds = 0;
+  for (;;) {
+    const int* cPrev = a.choice[cur];
+    int* cNew = a.choice[cur ^ 1];
+    const int* bPrev = a.closedAt[cur];
+    int* bNew = a.closedAt[cur ^ 1];
+    int changed = 0;
+    for (int i = tid; i < a.nPts; i += GUIDED_THREADS) {
+      int c;
+      if (rounds == 0) {
+        c = points_choice(a, i, bPrev, true);
+      } else {
+        const int cnt = a.candCount[i];
+        c = cnt >= 0 ? points_choice_cached(a, i, bPrev, cnt) : points_choice(a, i, bPrev, false);
+      }
+      cNew[i] = c;
+      changed |= (c != cPrev[i]) ? 1 : 0;
+    }
+    for (int i2 = tid; i2 < a.n; i2 += GUIDED_THREADS)
+      bNew[i2] = (a.state && a.state[i2] == 1) ? -1 : OPEN;
+    __syncthreads();
+    for (int i = tid; i < a.nPts; i += GUIDED_THREADS) {
+      const int c = cNew[i];
+      if (c >= 0 && a.ptObs[i]) atomicMin(&bNew[c], i);
+    }
+    ++rounds;
+    cur ^= 1;
+    const int any = __syncthreads_or(changed);
+    if (!any || rounds > a.nPts + 1) break;
+  }
+  // matcher.cc:127-138: the last map point that took a keypoint keeps it; every take counts
+  const int* choice = a.choice[cur];
+  for (int i2 = tid; i2 < a.n; i2 += GUIDED_THREADS) a.assigned[i2] = -1;
+  __syncthreads();
+  for (int i = tid; i < a.nPts; i += GUIDED_THREADS) {
+    const int c = choice[i];
+    if (c >= 0) {
+      atomicMax(&a.assigned[c], i);
+      atomicAdd(&nmS, 1);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) { a.summary[0] = nmS; a.summary[1] = rounds; }
+}
+
 struct InitArgs {
   // frame 1 (reference frame of the initialisation)
   const GKP* K1;
@@ -475,6 +629,29 @@ void launch_search_by_projection_last(const uint8_t* d_lastValid, const float* d
   a.cand = (uint32_t*)(a.candCount + nLast);
   a.assigned = d_assigned; a.summary = d_summary;
   hipLaunchKernelGGL(k_search_by_projection_last, dim3(1), dim3(GUIDED_THREADS), 0, s, a);
+}
+
+void launch_search_by_projection_points(const uint8_t* d_inView, const float* d_proj, const float* d_projXR,
+                                        const int* d_level, const float* d_viewCos, const uint8_t* d_ptDesc,
+                                        const uint8_t* d_ptObs, int nPts, const float* d_kpsUn, const uint8_t* d_desc,
+                                        const float* d_uRight, const uint8_t* d_state, int n, const int* d_cellStart,
+                                        const int* d_entries, const float* bounds, const float* scaleFactors,
+                                        int nlevels, float th, float nnratio, int* d_work, int* d_assigned,
+                                        int* d_summary, hipStream_t s) {
+  PointsArgs a;
+  a.inView = d_inView; a.proj = d_proj; a.projXR = d_projXR; a.level = d_level; a.viewCos = d_viewCos;
+  a.ptDesc = (const uint32_t*)d_ptDesc; a.ptObs = d_ptObs; a.nPts = nPts;
+  a.grid = make_grid(d_kpsUn, d_cellStart, d_entries, bounds);
+  a.desc = (const uint32_t*)d_desc; a.uRight = d_uRight; a.state = d_state; a.n = n;
+  for (int l = 0; l < ORBX_MAX_LEVELS; ++l) a.scale[l] = l < nlevels ? scaleFactors[l] : 1.0f;
+  a.th = th; a.nnratio = nnratio;
+  // same layout as the last-frame matcher (projection_work_ints)
+  a.choice[0] = d_work; a.choice[1] = d_work + nPts;
+  a.closedAt[0] = d_work + 2 * (size_t)nPts; a.closedAt[1] = a.closedAt[0] + n;
+  a.candCount = a.closedAt[1] + n;
+  a.cand = (uint32_t*)(a.candCount + nPts);
+  a.assigned = d_assigned; a.summary = d_summary;
+  hipLaunchKernelGGL(k_search_by_projection_points, dim3(1), dim3(GUIDED_THREADS), 0, s, a);
 }
 
 void launch_search_for_initialization(const float* d_kps1Un, const uint8_t* d_desc1, int n1, float* d_prevMatched,

@@ -1,6 +1,6 @@
 """Host mirror of the guided matchers that walk the frame grid:
 ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) (core/lib/ORB/matcher.cc:
-1591-1808) and ORBmatcher::SearchForInitialization (:629-733).  The current frame is a frame of
+1591-1808), SearchByProjection(F, vpMapPoints, th) (:41-142) and SearchForInitialization (:629-733).  The current frame is a frame of
 an ORBextractor's last batch for which grid.frame_grid_batch() has run; all device work runs
 in liborbx_hip.so."""
 import ctypes as C
@@ -37,6 +37,35 @@ def search_by_projection_last(ex, frame, last_valid, uv, invz, last_octave, last
         lo.ctypes.data_as(_i32p), la.ctypes.data_as(_f32p), ptr(ld), ptr(lobs), ptr(ur), ptr(st), float(th),
         int(bool(forward)), int(bool(backward)), float(mbf), int(bool(check_orientation)), ptr(out), cap,
         C.byref(n), C.byref(nm), C.byref(rounds)), "orbx_search_by_projection_last")
+    if ur is not None:
+        assert len(ur) >= n.value
+    if st is not None:
+        assert len(st) >= n.value
+    return nm.value, out[:n.value].copy(), rounds.value
+
+
+def search_by_projection_points(ex, frame, in_view, proj, proj_xr, level, view_cos, desc, obs, u_right=None,
+                                state=None, th=1.0, nnratio=0.8):
+    """ORBmatcher::SearchByProjection(F, vpMapPoints, th) (matcher.cc:41-142) -> (nmatches,
+    assigned[n], rounds).  assigned[i2] = index of the map point keypoint i2 received, -1 = none."""
+    iv = np.ascontiguousarray(in_view, np.uint8)
+    n_pts = len(iv)
+    pj = np.ascontiguousarray(proj, np.float32).reshape(-1, 2)
+    xr = np.ascontiguousarray(proj_xr, np.float32)
+    lv = np.ascontiguousarray(level, np.int32)
+    vc = np.ascontiguousarray(view_cos, np.float32)
+    pd = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    po = np.ascontiguousarray(obs, np.uint8)
+    assert len(pj) == len(xr) == len(lv) == len(vc) == len(pd) == len(po) == n_pts
+    cap = ex.max_keypoints()
+    ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+    st = None if state is None else np.ascontiguousarray(state, np.uint8)
+    out = np.zeros(cap, np.int32)
+    n, nm, rounds = C.c_int32(), C.c_int32(), C.c_int32()
+    check(lib().orbx_search_by_projection_points(
+        ex._h, int(frame), n_pts, ptr(iv), pj.ctypes.data_as(_f32p), xr.ctypes.data_as(_f32p),
+        lv.ctypes.data_as(_i32p), vc.ctypes.data_as(_f32p), ptr(pd), ptr(po), ptr(ur), ptr(st), float(th),
+        float(nnratio), ptr(out), cap, C.byref(n), C.byref(nm), C.byref(rounds)), "orbx_search_by_projection_points")
     if ur is not None:
         assert len(ur) >= n.value
     if st is not None:

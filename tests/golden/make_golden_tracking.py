@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Generates tests/golden/guided_376x240.npz and bow_376x240.npz from the CPU oracle: inputs and
-expected outputs of SearchByProjection(Frame, LastFrame), SearchForInitialization and
+expected outputs of SearchByProjection(Frame, LastFrame), SearchByProjection(Frame, map points),
+SearchForInitialization and
 ComputeBoW on a seeded synthetic frame pair.  Like the other fixtures they pin GPU <-> oracle
 parity and guard the oracle against drift.
 
@@ -51,7 +52,23 @@ def main():
                                           bounds, cs, ent, sf, th, 0, 0, mbf, True)
     prev = np.stack([ka["x"], ka["y"]], 1).astype(np.float32)
     ni, m12, pm = O.search_for_initialization(ka, da, un, db, bounds, cs, ent, prev, 60, 0.9, True)
-    np.savez_compressed(os.path.join(HERE, "guided_376x240.npz"), seed=SEED, shift=SHIFT, w=W, h=H,
+    # the same keypoints as map points of the local map, two per keypoint (matcher.cc:41-142)
+    rng2 = np.random.default_rng(18)
+    kp2, dp2 = np.concatenate([ka, ka]), np.concatenate([da, da])
+    n2 = len(kp2)
+    pt_proj = np.stack([kp2["x"] + SHIFT + rng2.uniform(-4, 4, n2), kp2["y"] + rng2.uniform(-4, 4, n2)], 1).astype(np.float32)
+    pt_proj_xr = (pt_proj[:, 0] - rng2.uniform(1, 30, n2)).astype(np.float32)
+    pt_level = np.clip(kp2["octave"] + rng2.integers(-1, 2, n2), 0, PARAMS[2] - 1).astype(np.int32)
+    pt_view_cos = np.where(rng2.random(n2) < 0.5, 0.9995, rng2.uniform(0.5, 0.998, n2)).astype(np.float32)
+    pt_in_view = (rng2.random(n2) < 0.9).astype(np.uint8)
+    pt_obs = (rng2.random(n2) < 0.7).astype(np.uint8)
+    pt_th, pt_ratio = 3.0, 0.8
+    np_, pasg = O.search_by_projection_points(pt_in_view, pt_proj, pt_proj_xr, pt_level, pt_view_cos, dp2, pt_obs, un, db,
+                                              u_right, state, bounds, cs, ent, sf, pt_th, pt_ratio)
+    print("guided", np_, "map-point matches of", n2)
+    np.savez_compressed(os.path.join(HERE, "guided_376x240.npz"), pt_in_view=pt_in_view, pt_proj=pt_proj,
+                        pt_proj_xr=pt_proj_xr, pt_level=pt_level, pt_view_cos=pt_view_cos, pt_obs=pt_obs, pt_th=pt_th,
+                        pt_ratio=pt_ratio, pt_nmatches=np_, pt_assigned=pasg, seed=SEED, shift=SHIFT, w=W, h=H,
                         params=np.array(PARAMS, np.float64), a_crc32=zlib.crc32(a.tobytes()),
                         b_crc32=zlib.crc32(b.tobytes()), last_keypoints=ka, last_descriptors=da, uv=uv, invz=invz,
                         valid=valid, obs=obs, state=state, u_right=u_right, th=th, mbf=mbf, nmatches=nm,

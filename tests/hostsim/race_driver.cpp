@@ -192,6 +192,43 @@ int main(int argc, char** argv) {
     }
   }
 
+  step("search by projection of map points");
+  {
+    // three map points per keypoint of frame 0, each with its own jitter
+    const int np = 3 * n[0];
+    std::vector<uint8_t> view(np), obs(np), state(cap);
+    std::vector<float> proj(2 * (size_t)np), xr(np), vcos(np), ur(cap);
+    std::vector<int32_t> lvl(np), assigned(cap);
+    std::vector<uint8_t> pd;
+    std::uniform_real_distribution<float> jitter(-5.f, 5.f);
+    for (int c = 0; c < 3; ++c) {
+      const std::vector<uint8_t> d = perturbed(desc.data(), n[0], 10 * c, rng);
+      pd.insert(pd.end(), d.begin(), d.end());
+    }
+    for (int i = 0; i < np; ++i) {
+      const orbx_keypoint& kp = kun[i % n[0]];
+      view[i] = rng() % 10 != 0;
+      obs[i] = rng() % 4 != 0;
+      proj[2 * i] = kp.x + jitter(rng);
+      proj[2 * i + 1] = kp.y + jitter(rng);
+      xr[i] = proj[2 * i] - 5.0f;
+      vcos[i] = (rng() & 1) ? 0.9995f : 0.9f;
+      lvl[i] = std::min(prm.nlevels - 1, kp.octave + (int)(rng() % 2));
+    }
+    for (int i = 0; i < cap; ++i) {
+      state[i] = (uint8_t)(rng() % 6 == 0 ? 1 + rng() % 2 : 0);
+      ur[i] = (rng() % 3 == 0) ? kun[i % std::max(1, n[0])].x - 5.0f : -1.0f;
+    }
+    int nout = 0, nm = 0, rounds = 0;
+    for (int variant = 0; variant < 2; ++variant) {
+      CHECK(orbx_search_by_projection_points(left, 0, np, view.data(), proj.data(), xr.data(), lvl.data(), vcos.data(),
+                                             pd.data(), obs.data(), variant ? ur.data() : nullptr,
+                                             variant ? state.data() : nullptr, variant ? 1.0f : 4.0f, 0.8f,
+                                             assigned.data(), cap, &nout, &nm, &rounds));
+      fprintf(stderr, "race_driver:   variant %d: %d matches in %d rounds\n", variant, nm, rounds);
+    }
+  }
+
   step("search for initialization");
   {
     // F1 = the same keypoints with perturbed descriptors: neighbours compete for the same

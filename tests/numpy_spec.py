@@ -544,6 +544,85 @@ def search_by_projection_last(last_valid, uv, invz, last_octave, last_angle, las
     return nm, assigned
 
 
+def _point_candidates(in_view, proj, proj_xr, level, view_cos, pt_desc, k, d, u_right, grid, bounds, scale, th):
+    """Per map point the keypoints of its window with their distances (matcher.cc:60-101), before
+    anything that depends on other map points."""
+    cand = []
+    for i in range(len(in_view)):
+        lst = []
+        if in_view[i]:
+            r = F32(2.5) if float(F32(view_cos[i])) > 0.998 else F32(4.0)
+            if float(F32(th)) != 1.0:
+                r = r * F32(th)
+            o = int(level[i])
+            radius = r * scale[o]
+            for i2 in features_in_area(k, grid, bounds, F32(proj[i][0]), F32(proj[i][1]), radius, o - 1, o):
+                if u_right is not None and u_right[i2] > 0:
+                    if abs(F32(proj_xr[i]) - u_right[i2]) > radius:
+                        continue
+                lst.append((i2, hamming(pt_desc[i], d[i2]), int(k["octave"][i2])))
+        cand.append(lst)
+    return cand
+
+
+def _point_choice(lst, is_blocked, nnratio):
+    best = best2 = 256
+    lvl = lvl2 = bi = -1
+    for i2, dist, octave in lst:
+        if is_blocked(i2):
+            continue
+        if dist < best:
+            best2, best, lvl2, lvl, bi = best, dist, lvl, octave, i2
+        elif dist < best2:
+            lvl2, best2 = octave, dist
+    if best <= 100 and not (lvl == lvl2 and F32(best) > F32(nnratio) * F32(best2)):
+        return bi
+    return -1
+
+
+def search_by_projection_points(in_view, proj, proj_xr, level, view_cos, pt_desc, pt_obs, k, d, u_right, state,
+                                grid, bounds, scale, th, nnratio):
+    """ORBmatcher::SearchByProjection(F, vpMapPoints, th, ...), matcher.cc:41-142, Nleft == -1."""
+    cand = _point_candidates(in_view, proj, proj_xr, level, view_cos, pt_desc, k, d, u_right, grid, bounds, scale, th)
+    assigned = [-1] * len(k)
+    blocked = [s == 1 for s in state]
+    nm = 0
+    for i in range(len(in_view)):
+        bi = _point_choice(cand[i], lambda i2: blocked[i2], nnratio)
+        if bi >= 0:
+            assigned[bi] = i
+            blocked[bi] = bool(pt_obs[i])
+            nm += 1
+    return nm, assigned
+
+
+def rounds_search_by_projection_points(in_view, proj, proj_xr, level, view_cos, pt_desc, pt_obs, k, d, u_right,
+                                       state, grid, bounds, scale, th, nnratio):
+    cand = _point_candidates(in_view, proj, proj_xr, level, view_cos, pt_desc, k, d, u_right, grid, bounds, scale, th)
+    n_pts, n = len(in_view), len(k)
+    inf = n_pts + 1
+    block_time = [-1 if s == 1 else inf for s in state]
+    choice = [-1] * n_pts
+    rounds = 0
+    while True:
+        rounds += 1
+        new_choice = [_point_choice(cand[i], lambda i2, i=i: block_time[i2] < i, nnratio) for i in range(n_pts)]
+        new_block = [-1 if s == 1 else inf for s in state]
+        for i, c in enumerate(new_choice):
+            if c >= 0 and pt_obs[i]:
+                new_block[c] = min(new_block[c], i)
+        if new_choice == choice and new_block == block_time:
+            break
+        choice, block_time = new_choice, new_block
+    assigned = [-1] * n
+    nm = 0
+    for i, c in enumerate(choice):
+        if c >= 0:
+            assigned[c] = i
+            nm += 1
+    return nm, assigned, rounds
+
+
 # ---- the guided matchers as rounds of independent decisions (the form a GPU can run) ---------------
 # Both reference loops are greedy over the query index.  What a query may take depends only on
 # what queries with a LOWER index took, so the loop equals the unique fixed point of "every query

@@ -57,6 +57,8 @@ def lib():
                                                     C.c_int, C.c_float, C.c_int, C.c_void_p]
         L.orc_search_by_projection_last.argtypes = [C.c_void_p] * 7 + [C.c_int] + [C.c_void_p] * 4 + [C.c_int] + \
             [C.c_void_p] * 4 + [C.c_float, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]
+        L.orc_search_by_projection_points.argtypes = [C.c_void_p] * 7 + [C.c_int] + [C.c_void_p] * 4 + [C.c_int] + \
+            [C.c_void_p] * 4 + [C.c_float, C.c_float, C.c_void_p]
         _lib = L
     return _lib
 
@@ -304,6 +306,29 @@ def search_by_projection_last(last_valid, uv, invz, last_octave, last_angle, las
                                             _p(k), _p(d), _p(ur) if ur is not None else None, _p(st), len(k),
                                             _p(b), _p(cs), _p(ent), _p(sf), th, int(forward), int(backward), mbf,
                                             int(check_orientation), _p(out))
+    return n, out[:len(k)]
+
+
+def search_by_projection_points(in_view, proj, proj_xr, level, view_cos, pt_desc, pt_obs, k, d, u_right, state,
+                                bounds, cs, ent, scale_factors, th, nnratio):
+    iv = np.ascontiguousarray(in_view, np.uint8)
+    pj = np.ascontiguousarray(proj, np.float32)
+    xr = np.ascontiguousarray(proj_xr, np.float32)
+    lv = np.ascontiguousarray(level, np.int32)
+    vc = np.ascontiguousarray(view_cos, np.float32)
+    pd = np.ascontiguousarray(pt_desc, np.uint8)
+    po = np.ascontiguousarray(pt_obs, np.uint8)
+    k = np.ascontiguousarray(k, KP)
+    d = np.ascontiguousarray(d, np.uint8)
+    ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+    st = np.ascontiguousarray(state, np.uint8)
+    ent = np.ascontiguousarray(ent if len(ent) else np.zeros(1), np.int32)
+    b = np.ascontiguousarray(bounds, np.float32)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    out = np.zeros(max(len(k), 1), np.int32)
+    n = lib().orc_search_by_projection_points(_p(iv), _p(pj), _p(xr), _p(lv), _p(vc), _p(pd), _p(po), len(iv),
+                                              _p(k), _p(d), _p(ur) if ur is not None else None, _p(st), len(k),
+                                              _p(b), _p(cs), _p(ent), _p(sf), th, nnratio, _p(out))
     return n, out[:len(k)]
 
 

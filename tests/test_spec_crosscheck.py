@@ -204,6 +204,47 @@ def test_search_by_projection_last(oracle):
         assert (asg >= 0).sum() > 20
 
 
+def _map_points(rng, ka, da, kb, nlevels, shift=6, jitter=3.0):
+    """Map points seen from the first frame, projected into the second (which is shifted)."""
+    n = len(ka)
+    proj = np.stack([ka["x"] + shift + rng.uniform(-jitter, jitter, n), ka["y"] + rng.uniform(-jitter, jitter, n)],
+                    1).astype(np.float32)
+    proj_xr = (proj[:, 0] - rng.uniform(1, 30, n)).astype(np.float32)
+    level = np.clip(ka["octave"] + rng.integers(-1, 2, n), 0, nlevels - 1).astype(np.int32)
+    view_cos = np.where(rng.random(n) < 0.5, 0.9995, rng.uniform(0.5, 0.998, n)).astype(np.float32)
+    in_view = (rng.random(n) < 0.9).astype(np.uint8)
+    desc = da.copy()
+    flip = rng.random(n) < 0.5
+    desc[flip, rng.integers(0, 32)] ^= 0x5A
+    obs = (rng.random(n) < 0.8).astype(np.uint8)
+    state = rng.choice([0, 0, 0, 1, 2], len(kb)).astype(np.uint8)
+    u_right = np.where(rng.random(len(kb)) < 0.5, kb["x"] - rng.uniform(1, 30, len(kb)), -1).astype(np.float32)
+    return in_view, proj, proj_xr, level, view_cos, desc, obs, state, u_right
+
+
+def test_search_by_projection_points(oracle):
+    params, ka, da, kb, db, bounds, cs, ent = _two_frames(oracle)
+    rng = np.random.default_rng(9)
+    scale, _ = S.level_tables(params[2], params[1])
+    grid = S.frame_grid(kb, bounds)
+    in_view, proj, proj_xr, level, view_cos, desc, obs, state, u_right = _map_points(rng, ka, da, kb, params[2])
+    worst = 0
+    for ur, th, ratio, obs_p in [(None, 1.0, 0.8, 1.0), (u_right, 3.0, 0.8, 1.0), (u_right, 1.0, 0.6, 0.5),
+                                 (None, 5.0, 0.95, 0.0), (None, 15.0, 1.0, 0.7)]:
+        o = (obs & (rng.random(len(obs)) < obs_p)).astype(np.uint8) if obs_p < 1 else np.ones_like(obs)
+        n, asg = oracle.search_by_projection_points(in_view, proj, proj_xr, level, view_cos, desc, o, kb, db, ur, state,
+                                                    bounds, cs, ent, np.array(scale, np.float32), th, ratio)
+        sn, sasg = S.search_by_projection_points(in_view, proj, proj_xr, level, view_cos, desc, o, kb, db, ur, state,
+                                                 grid, bounds, scale, th, ratio)
+        assert n == sn and asg.tolist() == sasg, (th, ratio)
+        rn, rasg, rounds = S.rounds_search_by_projection_points(in_view, proj, proj_xr, level, view_cos, desc, o, kb,
+                                                                db, ur, state, grid, bounds, scale, th, ratio)
+        assert (n, asg.tolist()) == (rn, rasg), (th, ratio)
+        worst = max(worst, rounds)
+        assert (asg >= 0).sum() > 20
+    assert worst <= 10, worst
+
+
 def test_guided_matchers_as_rounds_equal_the_greedy_loops(oracle):
     """The data-parallel formulation planned for the device (rounds of independent decisions that
     only look at lower-indexed queries' claims) reproduces the reference's sequential loops, in a

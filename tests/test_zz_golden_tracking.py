@@ -40,6 +40,12 @@ def test_oracle_reproduces_guided_golden(oracle):
     ni, m12, pm = oracle.search_for_initialization(ka, da, un, db, bounds, cs, ent, prev, int(g["window"]),
                                                    float(g["nnratio"]), True)
     assert ni == int(g["init_nmatches"]) and np.array_equal(m12, g["matches12"]) and np.array_equal(pm, g["prev_matched"])
+    dp2 = np.concatenate([da, da])
+    npm, pasg = oracle.search_by_projection_points(g["pt_in_view"], g["pt_proj"], g["pt_proj_xr"], g["pt_level"],
+                                                   g["pt_view_cos"], dp2, g["pt_obs"], un, db, g["u_right"], g["state"],
+                                                   bounds, cs, ent, np.array(eb.tables()["scale"], np.float32),
+                                                   float(g["pt_th"]), float(g["pt_ratio"]))
+    assert npm == int(g["pt_nmatches"]) and np.array_equal(pasg, g["pt_assigned"])
 
 
 def test_oracle_reproduces_bow_golden(oracle):
@@ -69,6 +75,10 @@ def test_hip_reproduces_guided_golden():
     prev = np.stack([ka["x"], ka["y"]], 1).astype(np.float32)
     ni, m12, pm, _ = guided.search_for_initialization(ex, 0, ka, da, prev, int(g["window"]), float(g["nnratio"]), True)
     assert ni == int(g["init_nmatches"]) and np.array_equal(m12, g["matches12"]) and np.array_equal(pm, g["prev_matched"])
+    npm, pasg, _ = guided.search_by_projection_points(ex, 0, g["pt_in_view"], g["pt_proj"], g["pt_proj_xr"], g["pt_level"],
+                                                      g["pt_view_cos"], np.concatenate([da, da]), g["pt_obs"],
+                                                      g["u_right"], g["state"], float(g["pt_th"]), float(g["pt_ratio"]))
+    assert npm == int(g["pt_nmatches"]) and np.array_equal(pasg, g["pt_assigned"])
 
 
 @pytest.mark.gpu

@@ -199,6 +199,24 @@ def grid_and_matchers(rng, img, params):
                                                       use_state, th, fwd, bwd, 40.0, ori)
     assert n == want_n and np.array_equal(asg, want), "search by projection"
 
+    # the same keypoints as map points in view (several per keypoint)
+    copies = int(rng.integers(1, 4))
+    kp3, dp3 = np.concatenate([ka] * copies), np.concatenate([da] * copies)
+    n3 = len(kp3)
+    proj = np.stack([kp3["x"] + rng.uniform(-jit, jit, n3), kp3["y"] + rng.uniform(-jit, jit, n3)], 1).astype(np.float32)
+    proj_xr = (proj[:, 0] - rng.uniform(0, 30, n3)).astype(np.float32)
+    level = np.clip(kp3["octave"] + rng.integers(-1, 2, n3), 0, params[2] - 1).astype(np.int32)
+    vcos = np.where(rng.random(n3) < 0.5, 0.9995, rng.uniform(0.5, 0.998, n3)).astype(np.float32)
+    in_view = (rng.random(n3) < 0.9).astype(np.uint8)
+    obs3 = (rng.random(n3) < rng.choice([0.0, 0.6, 1.0])).astype(np.uint8)
+    th3, ratio3 = float(rng.choice([1.0, 3.0, 5.0, 15.0])), float(rng.choice([0.6, 0.8, 0.9, 1.0]))
+    want_n, want = oracle.search_by_projection_points(in_view, proj, proj_xr, level, vcos, dp3, obs3, un, d, use_ur,
+                                                      use_state if use_state is not None
+                                                      else np.zeros(len(k), np.uint8), b, cs, ent, sf, th3, ratio3)
+    n3m, asg3, rounds3 = guided.search_by_projection_points(ex, 0, in_view, proj, proj_xr, level, vcos, dp3, obs3,
+                                                            use_ur, use_state, th3, ratio3)
+    assert n3m == want_n and np.array_equal(asg3, want), "search by projection of map points"
+
     ka0 = ka.copy()
     if rng.random() < 0.7:
         ka0["octave"] = np.where(rng.random(n1) < 0.8, 0, ka0["octave"])
@@ -224,7 +242,8 @@ def grid_and_matchers(rng, img, params):
     assert np.array_equal(wi, rwi) and np.array_equal(ni, rni), "bow ids"
     assert np.array_equal(wv.view(np.uint64), rwv.view(np.uint64)), "bow values"
     assert np.array_equal(ns, rns) and np.array_equal(ft, rft), "feature vector"
-    return "proj %d in %d rounds, init %d in %d rounds, %d words" % (n, rounds, n2, rounds2, len(wi))
+    return "proj %d in %d rounds, points %d in %d rounds, init %d in %d rounds, %d words" % (
+        n, rounds, n3m, rounds3, n2, rounds2, len(wi))
 
 
 def knn_part(rng):
