@@ -358,6 +358,26 @@ int orbx_bow_transform_batch_device(orbx_extractor* ex, const orbx_vocabulary* v
 int orbx_bow_download(orbx_extractor* ex, int frame, uint32_t* word_ids, double* word_values, int* n_words,
                       uint32_t* node_ids, int32_t* node_start, uint32_t* features, int* n_nodes, int cap);
 
+/* ORBmatcher::SearchByBoW(pKF, F, vpMapPointMatches), core/lib/ORB/matcher.cc:
+ * 222-405, monocular / rectified case (F.Nleft == -1, no second camera): the
+ * matcher of Tracking::TrackReferenceKeyFrame and Relocalization.  F is frame
+ * `frame` of the last extraction on `f` for which
+ * orbx_bow_transform_batch_device has run (its FeatureVector and descriptors
+ * are read where they lie in device memory).  The keyframe arrives as host
+ * arrays over its n_kf keypoints:
+ *   kf_valid[i]  its map point i exists and is not bad (:252-258)
+ *   kf_angle[i]  pKF->mvKeysUn[i].angle (:321-325);  kf_desc  32 bytes each
+ *   pKF->mFeatVec as a CSR in ascending node id (the layout orbx_bow_download
+ *   returns): kf_node_ids[n_kf_nodes], kf_node_start[n_kf_nodes + 1], kf_features
+ * nnratio and check_orientation are the matcher's constructor arguments.
+ * matches[i2] (cap entries, *n_out used) = keyframe keypoint whose map point
+ * frame keypoint i2 received, -1 = none, -2 = received and cleared by the
+ * rotation check (:394-401).  *nmatches = the return value.  Blocks. */
+int orbx_search_by_bow(orbx_extractor* f, int frame, int n_kf, const uint8_t* kf_valid, const float* kf_angle,
+                       const uint8_t* kf_desc, int n_kf_nodes, const uint32_t* kf_node_ids,
+                       const int32_t* kf_node_start, const uint32_t* kf_features, float nnratio,
+                       int check_orientation, int32_t* matches, int cap, int* n_out, int* nmatches);
+
 /* ---- synthetic input ------------------------------------------------------- */
 /* Deterministic textured test frame (PCG32-seeded rectangles + noise + 3x3
  * box blur), written to dst (height rows of stride bytes).  Host only. */

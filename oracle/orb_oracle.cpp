@@ -1239,6 +1239,64 @@ int orc_search_by_projection_points(const uint8_t* inView, const float* proj, co
   return nmatches;
 }
 
+// ORBmatcher::SearchByBoW(pKF, F, vpMapPointMatches), core/lib/ORB/matcher.cc:222-405, for a
+// monocular or rectified frame (F.Nleft == -1, no second camera), on flat arrays.  Both feature
+// vectors (DBoW2::FeatureVector = std::map<NodeId, vector<unsigned>>) arrive as CSR in ascending
+// node id, the maps' iteration order: nodeIds[r], features[nodeStart[r] .. nodeStart[r+1]).
+//   kfValid[i]  the keyframe's map point i exists and is not bad (:252-258)
+//   kfAngle[i]  pKF->mvKeysUn[i].angle (:321-325);  fAngle[i2]  F.mvKeys[i2].angle (:328-331)
+// matches[i2] (nF entries) = keyframe keypoint whose map point frame keypoint i2 received, -1 none,
+// -2 received and cleared by the rotation check (:394-401).  Returns nmatches.
+int orc_search_by_bow(const uint8_t* kfValid, const float* kfAngle, const uint8_t* kfDesc, int nKfNodes,
+                      const uint32_t* kfNodeIds, const int* kfNodeStart, const uint32_t* kfFeatures,
+                      const float* fAngle, const uint8_t* fDesc, int nF, int nFNodes, const uint32_t* fNodeIds,
+                      const int* fNodeStart, const uint32_t* fFeatures, float nnratio, int checkOrientation,
+                      int* matches) {
+  const int TH_LOW = 50;
+  int nmatches = 0;
+  for (int i = 0; i < nF; ++i) matches[i] = -1;
+  std::vector<std::vector<int>> rotHist(kHistoLength);
+  int a = 0, b = 0;
+  while (a < nKfNodes && b < nFNodes) {
+    if (kfNodeIds[a] == fNodeIds[b]) {
+      for (int iKF = kfNodeStart[a]; iKF < kfNodeStart[a + 1]; ++iKF) {
+        const unsigned realIdxKF = kfFeatures[iKF];
+        if (!kfValid[realIdxKF]) continue;
+        int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+        for (int iF = fNodeStart[b]; iF < fNodeStart[b + 1]; ++iF) {
+          const unsigned realIdxF = fFeatures[iF];
+          if (matches[realIdxF] >= 0) continue;
+          const int dist = hamming256(kfDesc + (size_t)realIdxKF * 32, fDesc + (size_t)realIdxF * 32);
+          if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = (int)realIdxF; }
+          else if (dist < bestDist2) { bestDist2 = dist; }
+        }
+        if (bestDist1 <= TH_LOW) {
+          if ((float)bestDist1 < nnratio * (float)bestDist2) {
+            matches[bestIdxF] = (int)realIdxKF;
+            if (checkOrientation) rotHist[rotationBin(kfAngle[realIdxKF], fAngle[bestIdxF])].push_back(bestIdxF);
+            nmatches++;
+          }
+        }
+      }
+      ++a; ++b;
+    } else if (kfNodeIds[a] < fNodeIds[b]) {
+      ++a;   // lower_bound(Fit->first) in a sorted map: skip ahead
+    } else {
+      ++b;
+    }
+  }
+  if (checkOrientation) {
+    int sizes[kHistoLength], ind[3];
+    for (int i = 0; i < kHistoLength; ++i) sizes[i] = (int)rotHist[i].size();
+    orc_three_maxima(sizes, kHistoLength, ind);
+    for (int i = 0; i < kHistoLength; ++i) {
+      if (i == ind[0] || i == ind[1] || i == ind[2]) continue;
+      for (int i2 : rotHist[i]) { matches[i2] = -2; nmatches--; }
+    }
+  }
+  return nmatches;
+}
+
 }  // extern "C"
 
 // ---- bag of words (Frame::ComputeBoW, core/src/Frame.cc:764-769) -----------------------------

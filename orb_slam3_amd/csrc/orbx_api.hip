@@ -62,6 +62,11 @@ void launch_search_for_initialization(const float* d_kps1Un, const uint8_t* d_de
                                       const int* d_cellStart2, const int* d_entries2, const float* bounds2,
                                       float window, float nnratio, int checkOrientation, int* d_work,
                                       int* d_matches12, int* d_summary, hipStream_t s);
+void launch_search_by_bow(const uint8_t* d_kfValid, const float* d_kfAngle, const uint8_t* d_kfDesc, int nKfNodes,
+                          const uint32_t* d_kfNode, const int* d_kfStart, const uint32_t* d_kfFeat,
+                          const float* d_kps, const uint8_t* d_desc, const int* d_n, int cap, const uint32_t* d_fNode,
+                          const int* d_fStart, const uint32_t* d_fFeat, const int* d_fCount, float nnratio,
+                          int checkOrientation, int* d_matches, int* d_summary, hipStream_t s);
 void launch_search_by_projection_points(const uint8_t* d_inView, const float* d_proj, const float* d_projXR,
                                         const int* d_level, const float* d_viewCos, const uint8_t* d_ptDesc,
                                         const uint8_t* d_ptObs, int nPts, const float* d_kpsUn, const uint8_t* d_desc,
@@ -1278,6 +1283,74 @@ int orbx_bow_download(orbx_extractor* ex, int frame, uint32_t* word_ids, double*
                            hipMemcpyDeviceToHost, s));
   if (features && m) HIP_TRY(hipMemcpyAsync(features, b.fvFeat + fo, (size_t)m * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
+  return ORBX_OK;
+}
+
+int orbx_search_by_bow(orbx_extractor* f, int frame, int n_kf, const uint8_t* kf_valid, const float* kf_angle,
+                       const uint8_t* kf_desc, int n_kf_nodes, const uint32_t* kf_node_ids,
+                       const int32_t* kf_node_start, const uint32_t* kf_features, float nnratio,
+                       int check_orientation, int32_t* matches, int cap, int* n_out, int* nmatches) {
+  orbx_extractor* ex = f;
+  if (!ex || !ex->planned || !ex->d_bowBlock || frame < 0 || frame >= ex->bowFrames || n_kf < 0 ||
+      n_kf_nodes < 0 || cap < 0 || !nmatches)
+    return ORBX_ERR_BAD_ARG;
+  if (n_kf > 0 && (!kf_valid || !kf_angle || !kf_desc)) return ORBX_ERR_BAD_ARG;
+  if (n_kf_nodes > 0 && (!kf_node_ids || !kf_node_start || !kf_features)) return ORBX_ERR_BAD_ARG;
+  // the keyframe's feature vector must be a CSR in ascending node id over keypoints [0, n_kf)
+  int nFeat = 0;
+  if (n_kf_nodes > 0) {
+    if (kf_node_start[0] != 0) return ORBX_ERR_BAD_ARG;
+    for (int r = 0; r < n_kf_nodes; ++r) {
+      if (kf_node_start[r + 1] < kf_node_start[r]) return ORBX_ERR_BAD_ARG;
+      if (r > 0 && kf_node_ids[r] <= kf_node_ids[r - 1]) return ORBX_ERR_BAD_ARG;
+    }
+    nFeat = kf_node_start[n_kf_nodes];
+    for (int i = 0; i < nFeat; ++i)
+      if (kf_features[i] >= (uint32_t)n_kf) return ORBX_ERR_BAD_ARG;
+  }
+  if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  auto& last_hip_error = ex->last_hip_error;
+  hipStream_t s = ex->stream;
+  int n = 0;
+  HIP_TRY(hipMemcpyAsync(&n, ex->d_n + frame, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (n_out) *n_out = n;
+  *nmatches = 0;
+  if (n > cap) return ORBX_ERR_CAPACITY;
+  if (n > 0 && !matches) return ORBX_ERR_BAD_ARG;
+  if (n == 0) return ORBX_OK;
+  const size_t nk = (size_t)std::max(n_kf, 1), nn = (size_t)std::max(n_kf_nodes, 1), nf = (size_t)std::max(nFeat, 1);
+  const int kc = ex->hp.kp_cap;
+  Carver c;
+  const size_t oValid = c.add(nk), oAng = c.add(nk * 4), oDesc = c.add(nk * 32), oNode = c.add(nn * 4),
+               oStart = c.add((nn + 1) * 4), oFeat = c.add(nf * 4), oM = c.add((size_t)kc * 4), oSum = c.add(8);
+  uint8_t* d = nullptr;
+  hipError_t e = hipMallocAsync((void**)&d, c.total, s);
+  if (e != hipSuccess) { last_hip_error = e; return ORBX_ERR_HIP; }
+  auto up = [&](size_t off, const void* src, size_t bytes) {
+    if (e == hipSuccess && bytes) e = hipMemcpyAsync(d + off, src, bytes, hipMemcpyHostToDevice, s);
+  };
+  up(oValid, kf_valid, (size_t)n_kf); up(oAng, kf_angle, (size_t)n_kf * 4); up(oDesc, kf_desc, (size_t)n_kf * 32);
+  up(oNode, kf_node_ids, (size_t)n_kf_nodes * 4);
+  if (n_kf_nodes > 0) up(oStart, kf_node_start, ((size_t)n_kf_nodes + 1) * 4);
+  up(oFeat, kf_features, (size_t)nFeat * 4);
+  int sum[2] = {0, 0};
+  if (e == hipSuccess) {
+    const size_t base = (size_t)frame * kc;
+    const orbx::BowBuffers& b = ex->bow;
+    orbx::launch_search_by_bow(d + oValid, (const float*)(d + oAng), d + oDesc, n_kf_nodes,
+                               (const uint32_t*)(d + oNode), (const int*)(d + oStart), (const uint32_t*)(d + oFeat),
+                               ex->d_kps + base * 7, ex->d_desc + base * 32, ex->d_n + frame, kc, b.fvNode + base,
+                               b.fvStart + (size_t)frame * (kc + 1), b.fvFeat + base, b.fvCount + frame, nnratio,
+                               check_orientation != 0, (int*)(d + oM), (int*)(d + oSum), s);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(matches, d + oM, (size_t)n * 4, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(sum, d + oSum, 4, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFreeAsync(d, s);
+  if (e != hipSuccess) { last_hip_error = e; return ORBX_ERR_HIP; }
+  *nmatches = sum[0];
   return ORBX_OK;
 }
 

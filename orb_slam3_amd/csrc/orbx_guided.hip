@@ -5,6 +5,8 @@
 //   k_search_by_projection_points ORBmatcher::SearchByProjection(F, vpMapPoints, th, ...)
 //                                 matcher.cc:41-142 (the local-map matcher; same case)
 //   k_search_for_initialization   ORBmatcher::SearchForInitialization   matcher.cc:629-733
+//   k_bow_match_nodes / k_bow_match_finish   ORBmatcher::SearchByBoW(pKF, F, ...)  matcher.cc:222-405
+//                                 (same case; it walks the two feature vectors instead of the grid)
 //   three_maxima                  ORBmatcher::ComputeThreeMaxima        matcher.cc:1925-1957
 //
 // Both reference loops are greedy over the query index: what query i may take depends on what
@@ -593,6 +595,126 @@ __global__ __launch_bounds__(GUIDED_THREADS) void k_search_for_initialization(In
   if (tid == 0) { a.summary[0] = nmS; a.summary[1] = rounds; }
 }
 
+// ---- ORBmatcher::SearchByBoW(pKF, F, vpMapPointMatches), matcher.cc:222-405 ----------------------
+// A frame keypoint belongs to exactly one node of the frame's feature vector, so keyframe
+// features of different nodes never compete: one wave per keyframe node.  Inside a node the
+// reference is sequential over the keyframe's features (a frame keypoint that received a map
+// point is skipped by the later ones, :274-275); the wave keeps that order and spreads the
+// node's frame keypoints over its lanes.  The lane that owns a list position is the only one
+// that reads or writes matches[] for it, so "already matched" needs no exchange.
+struct BowMatchArgs {
+  // keyframe: per keypoint, then its feature vector as CSR in ascending node id
+  const uint8_t* kfValid;
+  const float* kfAngle;
+  const uint32_t* kfDesc;
+  int nKfNodes;
+  const uint32_t* kfNode;
+  const int* kfStart;
+  const uint32_t* kfFeat;
+  // frame: keypoints (angle), descriptors, its feature vector where the transform left it
+  const GKP* K;
+  const uint32_t* desc;
+  const int* nP;           // number of keypoints of the frame
+  const uint32_t* fNode;
+  const int* fStart;
+  const uint32_t* fFeat;
+  const int* fCount;       // number of nodes
+  float nnratio;
+  int checkOrientation;
+  int* matches;            // n, preset to -1 by the launcher
+  int* summary;            // [0] nmatches
+};
+
+#define BOWM_THREADS 256
+
+__global__ __launch_bounds__(BOWM_THREADS) void k_bow_match_nodes(BowMatchArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * (BOWM_THREADS / 64) + (threadIdx.x >> 6);   // keyframe node of this wave
+  if (r >= a.nKfNodes) return;
+  const uint32_t node = a.kfNode[r];
+  // the same node in the frame's vector (ascending ids): lower bound
+  int lo = 0, hi = *a.fCount;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (a.fNode[mid] < node) lo = mid + 1; else hi = mid;
+  }
+  if (lo >= *a.fCount || a.fNode[lo] != node) return;
+  const int fs = a.fStart[lo], nF = a.fStart[lo + 1] - fs;
+  for (int iKF = a.kfStart[r]; iKF < a.kfStart[r + 1]; ++iKF) {
+    const int realIdxKF = (int)a.kfFeat[iKF];
+    if (!a.kfValid[realIdxKF]) continue;
+    uint32_t dKF[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) dKF[w] = a.kfDesc[(size_t)realIdxKF * 8 + w];
+    // per lane: smallest (distance << 20 | list position) and the second smallest distance of
+    // its positions - what the scan of :270-288 leaves in bestDist1 / bestIdxF / bestDist2
+    uint32_t k1 = (256u << 20) | 0xFFFFFu;
+    int d2 = 256;
+    for (int c = lane; c < nF; c += 64) {
+      const int i2 = (int)a.fFeat[fs + c];
+      if (a.matches[i2] >= 0) continue;
+      const int dist = hamming_reg(dKF, a.desc + (size_t)i2 * 8);
+      const uint32_t key = ((uint32_t)dist << 20) | (uint32_t)c;
+      if (key < k1) { d2 = (int)(k1 >> 20); k1 = key; }
+      else if (dist < d2) d2 = dist;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const uint32_t ok1 = (uint32_t)__shfl_xor((int)k1, off);
+      const int od2 = __shfl_xor(d2, off);
+      const uint32_t hiKey = max(k1, ok1);
+      k1 = min(k1, ok1);
+      d2 = min(min(d2, od2), (int)(hiKey >> 20));
+    }
+    const int bestDist1 = (int)(k1 >> 20), pos = (int)(k1 & 0xFFFFFu);
+    if (bestDist1 <= TH_LOW && (float)bestDist1 < __fmul_rn(a.nnratio, (float)d2)) {
+      if ((pos & 63) == lane) a.matches[(int)a.fFeat[fs + pos]] = realIdxKF;   // the owner of that position
+    }
+  }
+}
+
+// rotation consistency (:387-402) and the count, one workgroup
+__global__ __launch_bounds__(GUIDED_THREADS) void k_bow_match_finish(BowMatchArgs a) {
+  __shared__ int hist[HISTO_LENGTH];
+  __shared__ int keep[3];
+  __shared__ int nmS;
+  const int tid = threadIdx.x, n = *a.nP;
+  if (tid < HISTO_LENGTH) hist[tid] = 0;
+  if (tid == 0) nmS = 0;
+  __syncthreads();
+  int mine = 0;
+  for (int i2 = tid; i2 < n; i2 += GUIDED_THREADS) {
+    const int m = a.matches[i2];
+    if (m >= 0) {
+      ++mine;
+      if (a.checkOrientation) {
+        const int bin = rotation_bin(a.kfAngle[m], a.K[i2].angle);
+        if (bin >= 0 && bin < HISTO_LENGTH) atomicAdd(&hist[bin], 1);
+      }
+    }
+  }
+  if (mine) atomicAdd(&nmS, mine);
+  __syncthreads();
+  if (a.checkOrientation) {
+    if (tid == 0) three_maxima(hist, HISTO_LENGTH, keep);
+    __syncthreads();
+    int cleared = 0;
+    for (int i2 = tid; i2 < n; i2 += GUIDED_THREADS) {
+      const int m = a.matches[i2];
+      if (m >= 0) {
+        const int bin = rotation_bin(a.kfAngle[m], a.K[i2].angle);
+        if (bin >= 0 && bin < HISTO_LENGTH && bin != keep[0] && bin != keep[1] && bin != keep[2]) {
+          a.matches[i2] = -2;
+          ++cleared;
+        }
+      }
+    }
+    if (cleared) atomicSub(&nmS, cleared);
+    __syncthreads();
+  }
+  if (tid == 0) a.summary[0] = nmS;
+}
+
 static GridView make_grid(const float* d_kpsUn, const int* d_cellStart, const int* d_entries, const float* bounds) {
   GridView g;
   g.U = (const GKP*)d_kpsUn;
@@ -652,6 +774,26 @@ void launch_search_by_projection_points(const uint8_t* d_inView, const float* d_
   a.cand = (uint32_t*)(a.candCount + nPts);
   a.assigned = d_assigned; a.summary = d_summary;
   hipLaunchKernelGGL(k_search_by_projection_points, dim3(1), dim3(GUIDED_THREADS), 0, s, a);
+}
+
+void launch_search_by_bow(const uint8_t* d_kfValid, const float* d_kfAngle, const uint8_t* d_kfDesc, int nKfNodes,
+                          const uint32_t* d_kfNode, const int* d_kfStart, const uint32_t* d_kfFeat,
+                          const float* d_kps, const uint8_t* d_desc, const int* d_n, int cap, const uint32_t* d_fNode,
+                          const int* d_fStart, const uint32_t* d_fFeat, const int* d_fCount, float nnratio,
+                          int checkOrientation, int* d_matches, int* d_summary, hipStream_t s) {
+  BowMatchArgs a;
+  a.kfValid = d_kfValid; a.kfAngle = d_kfAngle; a.kfDesc = (const uint32_t*)d_kfDesc; a.nKfNodes = nKfNodes;
+  a.kfNode = d_kfNode; a.kfStart = d_kfStart; a.kfFeat = d_kfFeat;
+  a.K = (const GKP*)d_kps; a.desc = (const uint32_t*)d_desc; a.nP = d_n;
+  a.fNode = d_fNode; a.fStart = d_fStart; a.fFeat = d_fFeat; a.fCount = d_fCount;
+  a.nnratio = nnratio; a.checkOrientation = checkOrientation;
+  a.matches = d_matches; a.summary = d_summary;
+  (void)hipMemsetAsync(d_matches, 0xFF, (size_t)cap * 4, s);   // -1: no map point yet (:226)
+  if (nKfNodes > 0) {
+    const int perBlock = BOWM_THREADS / 64;
+    hipLaunchKernelGGL(k_bow_match_nodes, dim3((nKfNodes + perBlock - 1) / perBlock), dim3(BOWM_THREADS), 0, s, a);
+  }
+  hipLaunchKernelGGL(k_bow_match_finish, dim3(1), dim3(GUIDED_THREADS), 0, s, a);
 }
 
 void launch_search_for_initialization(const float* d_kps1Un, const uint8_t* d_desc1, int n1, float* d_prevMatched,

@@ -73,6 +73,29 @@ def search_by_projection_points(ex, frame, in_view, proj, proj_xr, level, view_c
     return nm.value, out[:n.value].copy(), rounds.value
 
 
+def search_by_bow(ex, frame, kf_valid, kf_angle, kf_desc, kf_node_ids, kf_node_start, kf_features, nnratio=0.7,
+                  check_orientation=True):
+    """ORBmatcher::SearchByBoW(pKF, F, ...) (matcher.cc:222-405) -> (nmatches, matches[n]).  The
+    frame's bag of words must have been computed (bow.transform_batch); the keyframe's feature
+    vector is the CSR bow.download returns.  matches[i2] = keyframe keypoint, -1 none, -2 cleared."""
+    kv = np.ascontiguousarray(kf_valid, np.uint8)
+    ka = np.ascontiguousarray(kf_angle, np.float32)
+    kd = np.ascontiguousarray(kf_desc, np.uint8).reshape(-1, 32)
+    assert len(kv) == len(ka) == len(kd)
+    kn = np.ascontiguousarray(kf_node_ids, np.uint32)
+    ks = np.ascontiguousarray(kf_node_start, np.int32)
+    kf = np.ascontiguousarray(kf_features, np.uint32)
+    assert len(ks) == len(kn) + 1 or len(kn) == 0
+    cap = ex.max_keypoints()
+    out = np.zeros(cap, np.int32)
+    n, nm = C.c_int32(), C.c_int32()
+    check(lib().orbx_search_by_bow(ex._h, int(frame), len(kv), ptr(kv), ka.ctypes.data_as(_f32p), ptr(kd), len(kn),
+                                   ptr(kn), ks.ctypes.data_as(_i32p), ptr(kf), float(nnratio),
+                                   int(bool(check_orientation)), ptr(out), cap, C.byref(n), C.byref(nm)),
+          "orbx_search_by_bow")
+    return nm.value, out[:n.value].copy()
+
+
 def search_for_initialization(ex2, frame2, kps1_un, desc1, prev_matched, window_size=100, nnratio=0.9,
                               check_orientation=True):
     """-> (nmatches, matches12[n1], prev_matched[n1, 2] updated, rounds)."""

@@ -78,7 +78,16 @@ def main():
     arrays = voc_util.make_vocabulary(k, L, seed=9)
     voc = O.Vocabulary(arrays=(k, L) + arrays + (0,))
     wi, wv, nodes, ns, ft = voc.transform(db, 2)
-    np.savez_compressed(os.path.join(HERE, "bow_376x240.npz"), seed=SEED, shift=SHIFT, w=W, h=H,
+    # SearchByBoW with frame a as the keyframe (matcher.cc:222-405)
+    _, _, kf_nodes, kf_start, kf_feats = voc.transform(da, 2)
+    rng3 = np.random.default_rng(19)
+    kf_valid = (rng3.random(len(ka)) < 0.85).astype(np.uint8)
+    sb_n, sb_m = O.search_by_bow(kf_valid, ka["angle"], da, kf_nodes, kf_start, kf_feats, kb["angle"], db, nodes, ns, ft,
+                                 0.7, True)
+    print("bow", sb_n, "matches by bag of words")
+    np.savez_compressed(os.path.join(HERE, "bow_376x240.npz"), kf_angle=ka["angle"], kf_desc=da, kf_valid=kf_valid,
+                        kf_nodes=kf_nodes, kf_start=kf_start, kf_feats=kf_feats, sb_ratio=0.7, sb_nmatches=sb_n,
+                        sb_matches=sb_m, seed=SEED, shift=SHIFT, w=W, h=H,
                         params=np.array(PARAMS, np.float64), b_crc32=zlib.crc32(b.tobytes()), k=k, L=L, levelsup=2,
                         voc_parent=arrays[0], voc_leaf=arrays[1], voc_desc=arrays[2], voc_weight=arrays[3],
                         word_ids=wi, word_values=wv, node_ids=nodes, node_start=ns, features=ft)

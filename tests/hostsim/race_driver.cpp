@@ -281,6 +281,25 @@ int main(int argc, char** argv) {
         CHECK(orbx_bow_download(left, f, wid.data(), wv.data(), &nw, nid.data(), nstart.data(), feats.data(),
                                 &nnodes, cap));
     }
+    // the keyframe = the same frame with perturbed descriptors: its feature vector comes from a
+    // transform on the right handle's copy of it (extract + transform + download)
+    step("search by bag of words");
+    for (int levelsup : {1, 4}) {
+      CHECK(orbx_bow_transform_batch_device(left, voc, NF, levelsup));
+      CHECK(orbx_bow_transform_batch_device(right, voc, NF, levelsup));
+      std::vector<uint32_t> nid(cap), feats(cap);
+      std::vector<int32_t> nstart(cap + 1);
+      int nw = 0, nnodes = 0;
+      CHECK(orbx_bow_download(right, 0, nullptr, nullptr, &nw, nid.data(), nstart.data(), feats.data(), &nnodes, cap));
+      std::vector<uint8_t> valid(nR[0]);
+      std::vector<float> ang(nR[0]);
+      for (int i = 0; i < nR[0]; ++i) { valid[i] = rng() % 7 != 0; ang[i] = kpsR[i].angle; }
+      std::vector<int32_t> m(cap);
+      int nout = 0, nm = 0;
+      CHECK(orbx_search_by_bow(left, 0, nR[0], valid.data(), ang.data(), descR.data(), nnodes, nid.data(),
+                               nstart.data(), feats.data(), 0.9f, 1, m.data(), cap, &nout, &nm));
+      fprintf(stderr, "race_driver:   levelsup %d: %d nodes, %d matches\n", levelsup, nnodes, nm);
+    }
     orbx_vocabulary_destroy(voc);
   }
 

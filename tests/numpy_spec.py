@@ -623,6 +623,41 @@ def rounds_search_by_projection_points(in_view, proj, proj_xr, level, view_cos, 
     return nm, assigned, rounds
 
 
+def search_by_bow(kf_valid, kf_angle, kf_desc, kf_fv, f_angle, f_desc, f_fv, nnratio, check_orientation):
+    """ORBmatcher::SearchByBoW(pKF, F, ...), matcher.cc:222-405, Nleft == -1.  kf_fv / f_fv: dicts
+    node id -> list of feature indices (the FeatureVector maps)."""
+    matches = [-1] * len(f_angle)
+    hist = [[] for _ in range(HISTO_LENGTH)]
+    nm = 0
+    for node in sorted(set(kf_fv) & set(f_fv)):
+        for ikf in kf_fv[node]:
+            if not kf_valid[ikf]:
+                continue
+            best = best2 = 256
+            bi = -1
+            for i2 in f_fv[node]:
+                if matches[i2] >= 0:
+                    continue
+                dist = hamming(kf_desc[ikf], f_desc[i2])
+                if dist < best:
+                    best2, best, bi = best, dist, i2
+                elif dist < best2:
+                    best2 = dist
+            if best <= 50 and F32(best) < F32(nnratio) * F32(best2):
+                matches[bi] = ikf
+                nm += 1
+                if check_orientation:
+                    hist[rotation_bin(kf_angle[ikf], f_angle[bi])].append(bi)
+    if check_orientation:
+        keep = three_maxima([len(h) for h in hist])
+        for b in range(HISTO_LENGTH):
+            if b not in keep:
+                for i2 in hist[b]:
+                    matches[i2] = -2
+                    nm -= 1
+    return nm, matches
+
+
 # ---- the guided matchers as rounds of independent decisions (the form a GPU can run) ---------------
 # Both reference loops are greedy over the query index.  What a query may take depends only on
 # what queries with a LOWER index took, so the loop equals the unique fixed point of "every query

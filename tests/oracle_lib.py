@@ -59,6 +59,8 @@ def lib():
             [C.c_void_p] * 4 + [C.c_float, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]
         L.orc_search_by_projection_points.argtypes = [C.c_void_p] * 7 + [C.c_int] + [C.c_void_p] * 4 + [C.c_int] + \
             [C.c_void_p] * 4 + [C.c_float, C.c_float, C.c_void_p]
+        L.orc_search_by_bow.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_int] + \
+            [C.c_void_p] * 3 + [C.c_float, C.c_int, C.c_void_p]
         _lib = L
     return _lib
 
@@ -330,6 +332,26 @@ def search_by_projection_points(in_view, proj, proj_xr, level, view_cos, pt_desc
                                               _p(k), _p(d), _p(ur) if ur is not None else None, _p(st), len(k),
                                               _p(b), _p(cs), _p(ent), _p(sf), th, nnratio, _p(out))
     return n, out[:len(k)]
+
+
+def search_by_bow(kf_valid, kf_angle, kf_desc, kf_nodes, kf_start, kf_feats, f_angle, f_desc, f_nodes, f_start,
+                  f_feats, nnratio=0.7, check_orientation=True):
+    kv = np.ascontiguousarray(kf_valid, np.uint8)
+    ka = np.ascontiguousarray(kf_angle, np.float32)
+    kd = np.ascontiguousarray(kf_desc, np.uint8)
+    kn = np.ascontiguousarray(kf_nodes if len(kf_nodes) else np.zeros(1), np.uint32)
+    ks = np.ascontiguousarray(kf_start, np.int32)
+    kf = np.ascontiguousarray(kf_feats if len(kf_feats) else np.zeros(1), np.uint32)
+    fa = np.ascontiguousarray(f_angle, np.float32)
+    fd = np.ascontiguousarray(f_desc, np.uint8)
+    fn = np.ascontiguousarray(f_nodes if len(f_nodes) else np.zeros(1), np.uint32)
+    fs = np.ascontiguousarray(f_start, np.int32)
+    ff = np.ascontiguousarray(f_feats if len(f_feats) else np.zeros(1), np.uint32)
+    out = np.zeros(max(len(fa), 1), np.int32)
+    n = lib().orc_search_by_bow(_p(kv), _p(ka), _p(kd), len(kf_nodes), _p(kn), _p(ks), _p(kf), _p(fa), _p(fd),
+                                len(fa), len(f_nodes), _p(fn), _p(fs), _p(ff), nnratio, int(check_orientation),
+                                _p(out))
+    return n, out[:len(fa)]
 
 
 class Vocabulary:

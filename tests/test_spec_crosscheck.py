@@ -245,6 +245,27 @@ def test_search_by_projection_points(oracle):
     assert worst <= 10, worst
 
 
+def test_search_by_bow(oracle):
+    from tests import voc_util
+    params, ka, da, kb, db, bounds, cs, ent = _two_frames(oracle)
+    rng = np.random.default_rng(10)
+    for k, L, levelsup, ratio, ori in [(6, 3, 2, 0.7, True), (10, 2, 1, 0.9, True), (4, 3, 4, 0.75, False),
+                                       (5, 4, 2, 1.0, True)]:
+        arrays = voc_util.make_vocabulary(k, L, seed=k * 10 + L)
+        voc = oracle.Vocabulary(arrays=(k, L) + arrays + (0,))
+        _, _, an, as_, af = voc.transform(da, levelsup)       # the keyframe = frame a
+        _, _, bn, bs, bf = voc.transform(db, levelsup)
+        valid = (rng.random(len(ka)) < 0.85).astype(np.uint8)
+        n, m = oracle.search_by_bow(valid, ka["angle"], da, an, as_, af, kb["angle"], db, bn, bs, bf, ratio, ori)
+        kf_fv = {int(an[r]): af[as_[r]:as_[r + 1]].tolist() for r in range(len(an))}
+        f_fv = {int(bn[r]): bf[bs[r]:bs[r + 1]].tolist() for r in range(len(bn))}
+        sn, sm = S.search_by_bow(valid, ka["angle"], da, kf_fv, kb["angle"], db, f_fv, ratio, ori)
+        assert n == sn and m.tolist() == sm, (k, L, levelsup)
+        assert (m >= 0).sum() > 20
+        ok = m >= 0
+        assert (np.abs((kb["x"][ok] - ka["x"][m[ok]]) - 6) <= 2).mean() > 0.8     # the shift is found
+
+
 def test_guided_matchers_as_rounds_equal_the_greedy_loops(oracle):
     """The data-parallel formulation planned for the device (rounds of independent decisions that
     only look at lower-indexed queries' claims) reproduces the reference's sequential loops, in a

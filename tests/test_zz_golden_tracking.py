@@ -57,6 +57,9 @@ def test_oracle_reproduces_bow_golden(oracle):
     wi, wv, ni, ns, ft = voc.transform(db, int(g["levelsup"]))
     assert np.array_equal(wi, g["word_ids"]) and np.array_equal(wv.view(np.uint64), g["word_values"].view(np.uint64))
     assert np.array_equal(ni, g["node_ids"]) and np.array_equal(ns, g["node_start"]) and np.array_equal(ft, g["features"])
+    n, m = oracle.search_by_bow(g["kf_valid"], g["kf_angle"], g["kf_desc"], g["kf_nodes"], g["kf_start"], g["kf_feats"],
+                                kb["angle"], db, ni, ns, ft, float(g["sb_ratio"]), True)
+    assert n == int(g["sb_nmatches"]) and np.array_equal(m, g["sb_matches"])
 
 
 @pytest.mark.gpu
@@ -94,3 +97,7 @@ def test_hip_reproduces_bow_golden():
     wi, wv, ni, ns, ft = bow.download(ex, 0)
     assert np.array_equal(wi, g["word_ids"]) and np.array_equal(wv.view(np.uint64), g["word_values"].view(np.uint64))
     assert np.array_equal(ni, g["node_ids"]) and np.array_equal(ns, g["node_start"]) and np.array_equal(ft, g["features"])
+    from orb_slam3_amd import guided
+    n, m = guided.search_by_bow(ex, 0, g["kf_valid"], g["kf_angle"], g["kf_desc"], g["kf_nodes"], g["kf_start"],
+                                g["kf_feats"], float(g["sb_ratio"]), True)
+    assert n == int(g["sb_nmatches"]) and np.array_equal(m, g["sb_matches"])

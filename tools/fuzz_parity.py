@@ -242,8 +242,14 @@ def grid_and_matchers(rng, img, params):
     assert np.array_equal(wi, rwi) and np.array_equal(ni, rni), "bow ids"
     assert np.array_equal(wv.view(np.uint64), rwv.view(np.uint64)), "bow values"
     assert np.array_equal(ns, rns) and np.array_equal(ft, rft), "feature vector"
-    return "proj %d in %d rounds, points %d in %d rounds, init %d in %d rounds, %d words" % (
-        n, rounds, n3m, rounds3, n2, rounds2, len(wi))
+    # the "other frame" as a keyframe: its feature vector from the oracle's transform
+    _, _, an, as_, af = ovoc.transform(da, levelsup)
+    ratio_b = float(rng.choice([0.6, 0.75, 0.9, 1.0]))
+    want_nb, want_b = oracle.search_by_bow(valid, ka["angle"], da, an, as_, af, k["angle"], d, rni, rns, rft, ratio_b, ori)
+    nb, mb_ = guided.search_by_bow(ex, 0, valid, ka["angle"], da, an, as_, af, ratio_b, ori)
+    assert nb == want_nb and np.array_equal(mb_, want_b), "search by bag of words"
+    return "proj %d in %d rounds, points %d in %d rounds, init %d in %d rounds, %d words, %d by bow" % (
+        n, rounds, n3m, rounds3, n2, rounds2, len(wi), nb)
 
 
 def knn_part(rng):
