@@ -182,12 +182,16 @@ def stereo_bench(torch, orbx, dev, local_rank, batch=128, reps=5):
             "match_stage_ms_per_step": sec_match * 1e3, "matches_per_pair": nmatch}
 
 
-def bow_bench(torch, orbx, dev, local_rank, batch=256, reps=5, k=10, depth=5):
-    """Secondary metric (opt-in): frames/s of Frame::ComputeBoW on device-resident descriptors,
-    synthetic vocabulary of k^depth words (children = bit-flipped copies of their parent)."""
+def _bench_vocabulary(orbx, local_rank, k=10, depth=5):
+    """Synthetic vocabulary of k^depth words (children = bit-flipped copies of their parent)."""
     from tests import voc_util
     arrays = voc_util.make_vocabulary(k, depth, seed=1)
-    voc = orbx.bow.ORBVocabulary.from_arrays(k, depth, *arrays, device=local_rank)
+    return orbx.bow.ORBVocabulary.from_arrays(k, depth, *arrays, device=local_rank), arrays
+
+
+def bow_bench(torch, orbx, dev, local_rank, batch=256, reps=5, k=10, depth=5):
+    """Secondary metric (opt-in): frames/s of Frame::ComputeBoW on device-resident descriptors."""
+    voc, _ = _bench_vocabulary(orbx, local_rank, k, depth)
     distinct = 8
     imgs = np.stack([orbx.textured_frame(700 + i, W, H) for i in range(distinct)])
     d = torch.from_numpy(np.tile(imgs, ((batch + distinct - 1) // distinct, 1, 1))[:batch].copy()).to(dev)
@@ -229,9 +233,32 @@ def guided_bench(torch, orbx, dev, local_rank, reps=20):
     for _ in range(reps):
         orbx.guided.search_by_projection_last(*args, th=15.0)
     sec = (time.perf_counter() - t0) / reps
+    # the local-map matcher on three map points per keypoint, and SearchByBoW against frame a
+    kp3, dp3 = np.concatenate([ka] * 3), np.concatenate([da] * 3)
+    n3 = len(kp3)
+    proj = np.stack([kp3["x"] + shift + rng.uniform(-3, 3, n3), kp3["y"] + rng.uniform(-3, 3, n3)], 1).astype(np.float32)
+    pargs = (exb, 0, np.ones(n3, np.uint8), proj, proj[:, 0] - 5, kp3["octave"], np.full(n3, 0.9995, np.float32), dp3,
+             np.ones(n3, np.uint8))
+    nm3, _, rounds3 = orbx.guided.search_by_projection_points(*pargs, th=3.0)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        orbx.guided.search_by_projection_points(*pargs, th=3.0)
+    sec3 = (time.perf_counter() - t0) / reps
+    voc, _ = _bench_vocabulary(orbx, local_rank)
+    orbx.bow.transform_batch(exa, voc, 1, 4)
+    _, _, an, as_, af = orbx.bow.download(exa, 0)
+    orbx.bow.transform_batch(exb, voc, 1, 4)
+    bargs = (exb, 0, np.ones(len(ka), np.uint8), ka["angle"], da, an, as_, af)
+    nmb, _ = orbx.guided.search_by_bow(*bargs)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        orbx.guided.search_by_bow(*bargs)
+    secb = (time.perf_counter() - t0) / reps
     return {"metric": "SearchByProjection(Frame, LastFrame) ms per call (host arrays in and out)",
             "value": sec * 1e3, "unit": "ms", "higher_is_better": False, "queries": n_last, "matches": nm,
-            "rounds": rounds}
+            "rounds": rounds,
+            "local_map": {"ms": sec3 * 1e3, "map_points": n3, "matches": nm3, "rounds": rounds3},
+            "by_bow": {"ms": secb * 1e3, "keyframe_features": len(ka), "nodes": len(an), "matches": nmb}}
 
 
 def main():
