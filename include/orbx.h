@@ -292,6 +292,20 @@ int orbx_search_by_projection_last(orbx_extractor* cur, int frame, int n_last, c
                                    const uint8_t* last_obs, const float* u_right, const uint8_t* state,
                                    float th, int forward, int backward, float mbf, int check_orientation,
                                    int32_t* assigned, int cap, int* n_out, int* nmatches, int* rounds);
+/* ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist),
+ * core/lib/ORB/matcher.cc:1810-1923 (relocalisation).  One entry per keypoint
+ * of the keyframe; the caller's part is :1826-1853:
+ *   kf_valid[i]  a map point exists, is not bad, is not in sAlreadyFound, and its
+ *                distance to the camera centre is inside its invariance range
+ *   uv           its projection; level[i] = PredictScale(dist3D, &CurrentFrame)
+ *   kf_angle[i]  pKF->mvKeysUn[i].angle;  kf_desc  the map point's descriptor
+ * has_point[i2] (0 or 1; NULL = none): CurrentFrame.mvpMapPoints[i2] is not null (:1872).
+ * orb_dist in [0, 255].  Outputs as in orbx_search_by_projection_last. */
+int orbx_search_by_projection_keyframe(orbx_extractor* cur, int frame, int n_kf, const uint8_t* kf_valid,
+                                       const float* uv, const int32_t* level, const float* kf_angle,
+                                       const uint8_t* kf_desc, const uint8_t* has_point, float th, int orb_dist,
+                                       int check_orientation, int32_t* assigned, int cap, int* n_out,
+                                       int* nmatches, int* rounds);
 /* ORBmatcher::SearchByProjection(F, vpMapPoints, th, bFarPoints, thFarPoints),
  * core/lib/ORB/matcher.cc:41-142, monocular / rectified case (Nleft == -1): the
  * local-map matcher of Tracking::SearchLocalPoints.  F is frame `frame` of the

@@ -1239,6 +1239,64 @@ int orc_search_by_projection_points(const uint8_t* inView, const float* proj, co
   return nmatches;
 }
 
+// ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist), core/lib/ORB/
+// matcher.cc:1810-1923 (relocalisation), on flat arrays.  Per keypoint of the keyframe, the
+// caller's part (:1826-1853):
+//   kfValid[i]   a map point exists, is not bad, is not in sAlreadyFound, and its distance to the
+//                camera centre lies inside its scale-invariance range
+//   uv[2i..]     its projection;  level[i]  PredictScale(dist3D);  kfAngle[i]  pKF->mvKeysUn[i].angle
+// hasPoint[i2]: CurrentFrame.mvpMapPoints[i2] is not null (any map point closes the keypoint, :1872).
+// assigned / return value as in orc_search_by_projection_last.
+int orc_search_by_projection_keyframe(const uint8_t* kfValid, const float* uv, const int* level,
+                                      const float* kfAngle, const uint8_t* kfDesc, int nKf, const void* kpsUn28,
+                                      const uint8_t* desc, const uint8_t* hasPoint, int n, const float* bounds,
+                                      const int* cellStart, const int* entries, const float* scaleFactors,
+                                      float th, int orbDist, int checkOrientation, int* assigned) {
+  const KeyPoint* K = (const KeyPoint*)kpsUn28;
+  int nmatches = 0;
+  for (int i = 0; i < n; ++i) assigned[i] = -1;
+  std::vector<uint8_t> taken(std::max(n, 1));
+  for (int i = 0; i < n; ++i) taken[i] = hasPoint[i] != 0;
+  std::vector<std::vector<int>> rotHist(kHistoLength);
+  std::vector<int> idx(std::max(n, 1));
+  for (int i = 0; i < nKf; ++i) {
+    if (!kfValid[i]) continue;
+    const float u = uv[2 * i], v = uv[2 * i + 1];
+    if (u < bounds[0] || u > bounds[1]) continue;
+    if (v < bounds[2] || v > bounds[3]) continue;
+    const int nPredictedLevel = level[i];
+    const float radius = th * scaleFactors[nPredictedLevel];
+    const int found = orc_features_in_area(bounds, kpsUn28, cellStart, entries, u, v, radius, nPredictedLevel - 1,
+                                           nPredictedLevel + 1, idx.data(), n);
+    if (found == 0) continue;
+    int bestDist = 256, bestIdx2 = -1;
+    for (int c = 0; c < found; ++c) {
+      const int i2 = idx[c];
+      if (taken[i2]) continue;
+      const int dist = hamming256(kfDesc + (size_t)i * 32, desc + (size_t)i2 * 32);
+      if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+    }
+    // (with ORBdist >= 256 and no free candidate the reference writes mvpMapPoints[-1]; callers
+    // pass 64 or 100, and this restatement requires a candidate)
+    if (bestDist <= orbDist && bestIdx2 >= 0) {
+      assigned[bestIdx2] = i;
+      taken[bestIdx2] = 1;
+      nmatches++;
+      if (checkOrientation) rotHist[rotationBin(kfAngle[i], K[bestIdx2].angle)].push_back(bestIdx2);
+    }
+  }
+  if (checkOrientation) {
+    int sizes[kHistoLength], ind[3];
+    for (int i = 0; i < kHistoLength; ++i) sizes[i] = (int)rotHist[i].size();
+    orc_three_maxima(sizes, kHistoLength, ind);
+    for (int i = 0; i < kHistoLength; ++i) {
+      if (i == ind[0] || i == ind[1] || i == ind[2]) continue;
+      for (int i2 : rotHist[i]) { assigned[i2] = -2; nmatches--; }
+    }
+  }
+  return nmatches;
+}
+
 // ORBmatcher::SearchByBoW(pKF, F, vpMapPointMatches), core/lib/ORB/matcher.cc:222-405, for a
 // monocular or rectified frame (F.Nleft == -1, no second camera), on flat arrays.  Both feature
 // vectors (DBoW2::FeatureVector = std::map<NodeId, vector<unsigned>>) arrive as CSR in ascending

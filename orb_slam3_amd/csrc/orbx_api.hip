@@ -55,8 +55,8 @@ void launch_search_by_projection_last(const uint8_t* d_lastValid, const float* d
                                       const uint8_t* d_desc, const float* d_uRight, const uint8_t* d_state, int n,
                                       const int* d_cellStart, const int* d_entries, const float* bounds,
                                       const float* scaleFactors, int nlevels, float th, int forward, int backward,
-                                      float mbf, int checkOrientation, int* d_work, int* d_assigned, int* d_summary,
-                                      hipStream_t s);
+                                      float mbf, int checkOrientation, int maxDist, int* d_work, int* d_assigned,
+                                      int* d_summary, hipStream_t s);
 void launch_search_for_initialization(const float* d_kps1Un, const uint8_t* d_desc1, int n1, float* d_prevMatched,
                                       const float* d_kps2Un, const uint8_t* d_desc2, int n2,
                                       const int* d_cellStart2, const int* d_entries2, const float* bounds2,
@@ -1039,12 +1039,15 @@ struct Carver {
 const int kGuidedMaxQueries = 1 << 20;
 }  // namespace
 
-int orbx_search_by_projection_last(orbx_extractor* cur, int frame, int n_last, const uint8_t* last_valid,
-                                   const float* uv, const float* invz, const int32_t* last_octave,
-                                   const float* last_angle, const uint8_t* last_desc, const uint8_t* last_obs,
-                                   const float* u_right, const uint8_t* state, float th, int forward,
-                                   int backward, float mbf, int check_orientation, int32_t* assigned, int cap,
-                                   int* n_out, int* nmatches, int* rounds) {
+namespace {
+// the last-frame matcher and the keyframe matcher: one loop, the second with a caller-given
+// distance limit, every keypoint with a map point closed, every assignment closing
+int search_by_projection(orbx_extractor* cur, int frame, int n_last, const uint8_t* last_valid, const float* uv,
+                         const float* invz, const int32_t* last_octave, const float* last_angle,
+                         const uint8_t* last_desc, const uint8_t* last_obs, const float* u_right,
+                         const uint8_t* state, float th, int forward, int backward, float mbf,
+                         int check_orientation, int max_dist, int32_t* assigned, int cap, int* n_out, int* nmatches,
+                         int* rounds) {
   orbx_extractor* ex = cur;
   if (!ex || !ex->planned || !ex->d_kpsUn || frame < 0 || frame >= ex->gridFrames || n_last < 0 ||
       n_last > kGuidedMaxQueries || cap < 0 || !nmatches)
@@ -1093,7 +1096,7 @@ int orbx_search_by_projection_last(orbx_extractor* cur, int frame, int n_last, c
         (const float*)(d + oAng), d + oDesc, d + oObs, n_last, ex->d_kpsUn + base * 7, ex->d_desc + base * 32,
         u_right ? (const float*)(d + oUr) : nullptr, state ? d + oState : nullptr, n,
         ex->d_cellStart + (size_t)frame * (ORBX_GRID_CELLS + 1), ex->d_cellEntries + base, ex->gridBounds,
-        ex->scale.data(), ex->prm.nlevels, th, forward != 0, backward != 0, mbf, check_orientation != 0,
+        ex->scale.data(), ex->prm.nlevels, th, forward != 0, backward != 0, mbf, check_orientation != 0, max_dist,
         (int*)(d + oWork), (int*)(d + oAsg), (int*)(d + oSum), s);
     e = hipGetLastError();
   }
@@ -1105,6 +1108,38 @@ int orbx_search_by_projection_last(orbx_extractor* cur, int frame, int n_last, c
   *nmatches = sum[0];
   if (rounds) *rounds = sum[1];
   return ORBX_OK;
+}
+}  // namespace
+
+int orbx_search_by_projection_last(orbx_extractor* cur, int frame, int n_last, const uint8_t* last_valid,
+                                   const float* uv, const float* invz, const int32_t* last_octave,
+                                   const float* last_angle, const uint8_t* last_desc, const uint8_t* last_obs,
+                                   const float* u_right, const uint8_t* state, float th, int forward,
+                                   int backward, float mbf, int check_orientation, int32_t* assigned, int cap,
+                                   int* n_out, int* nmatches, int* rounds) {
+  return search_by_projection(cur, frame, n_last, last_valid, uv, invz, last_octave, last_angle, last_desc, last_obs,
+                              u_right, state, th, forward, backward, mbf, check_orientation, 100 /* TH_HIGH */,
+                              assigned, cap, n_out, nmatches, rounds);
+}
+
+int orbx_search_by_projection_keyframe(orbx_extractor* cur, int frame, int n_kf, const uint8_t* kf_valid,
+                                       const float* uv, const int32_t* level, const float* kf_angle,
+                                       const uint8_t* kf_desc, const uint8_t* has_point, float th, int orb_dist,
+                                       int check_orientation, int32_t* assigned, int cap, int* n_out,
+                                       int* nmatches, int* rounds) {
+  if (n_kf < 0 || n_kf > kGuidedMaxQueries || orb_dist < 0 || orb_dist > 255) return ORBX_ERR_BAD_ARG;
+  try {
+    // in the terms of the shared loop: nothing is behind the camera, every map point has
+    // observations (an assignment closes the keypoint, matcher.cc:1872), and a keypoint that
+    // holds any map point is closed from the start
+    const std::vector<float> invz((size_t)n_kf, 1.0f);
+    const std::vector<uint8_t> obs((size_t)n_kf, 1);
+    return search_by_projection(cur, frame, n_kf, kf_valid, uv, invz.data(), level, kf_angle, kf_desc, obs.data(),
+                                nullptr, has_point, th, 0, 0, 0.0f, check_orientation, orb_dist, assigned, cap,
+                                n_out, nmatches, rounds);
+  } catch (...) {
+    return ORBX_ERR_UNSUPPORTED;
+  }
 }
 
 int orbx_search_by_projection_points(orbx_extractor* f, int frame, int n_points, const uint8_t* in_view,

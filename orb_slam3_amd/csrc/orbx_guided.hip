@@ -1,7 +1,9 @@
 // Guided matchers on a device-resident frame (undistorted keypoints, descriptors and the
 // 64 x 48 frame grid of orbx_grid.hip):
 //   k_search_by_projection_last   ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono)
-//                                 core/lib/ORB/matcher.cc:1591-1808 (monocular / rectified case)
+//                                 core/lib/ORB/matcher.cc:1591-1808 (monocular / rectified case);
+//                                 SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist),
+//                                 :1810-1923, is the same loop with other inputs
 //   k_search_by_projection_points ORBmatcher::SearchByProjection(F, vpMapPoints, th, ...)
 //                                 matcher.cc:41-142 (the local-map matcher; same case)
 //   k_search_for_initialization   ORBmatcher::SearchForInitialization   matcher.cc:629-733
@@ -151,6 +153,7 @@ struct ProjectionArgs {
   float scale[ORBX_MAX_LEVELS];
   float th, mbf;
   int forward, backward, checkOrientation;
+  int maxDist;             // TH_HIGH for the last-frame matcher, ORBdist for the keyframe one (:1885)
   // work arrays: two generations of choices (nLast) and of closing times (n); the candidate
   // lists of round 1, slot-major ([GUIDED_CACHE][nLast]) so that a wave reads them coalesced
   int* choice[2];
@@ -202,7 +205,7 @@ __device__ int projection_choice(const ProjectionArgs& a, int i, const int* clos
     if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
   });
   if (store) a.candCount[i] = k <= GUIDED_CACHE ? k : -1;
-  return bestDist <= TH_HIGH ? bestIdx2 : -1;
+  return bestDist <= a.maxDist ? bestIdx2 : -1;
 }
 
 // the same decision from the remembered candidates (same order, so the same ties)
@@ -214,7 +217,7 @@ __device__ int projection_choice_cached(const ProjectionArgs& a, int i, const in
     if (coherent_load(&closedAt[i2]) < i) continue;
     if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
   }
-  return bestDist <= TH_HIGH ? bestIdx2 : -1;
+  return bestDist <= a.maxDist ? bestIdx2 : -1;
 }
 
 __global__ __launch_bounds__(GUIDED_THREADS) void k_search_by_projection_last(ProjectionArgs a) {
@@ -736,9 +739,10 @@ void launch_search_by_projection_last(const uint8_t* d_lastValid, const float* d
                                       const uint8_t* d_desc, const float* d_uRight, const uint8_t* d_state, int n,
                                       const int* d_cellStart, const int* d_entries, const float* bounds,
                                       const float* scaleFactors, int nlevels, float th, int forward, int backward,
-                                      float mbf, int checkOrientation, int* d_work, int* d_assigned, int* d_summary,
-                                      hipStream_t s) {
+                                      float mbf, int checkOrientation, int maxDist, int* d_work, int* d_assigned,
+                                      int* d_summary, hipStream_t s) {
   ProjectionArgs a;
+  a.maxDist = maxDist;
   a.lastValid = d_lastValid; a.uv = d_uv; a.invz = d_invz; a.lastOctave = d_lastOctave;
   a.lastAngle = d_lastAngle; a.lastDesc = (const uint32_t*)d_lastDesc; a.lastObs = d_lastObs; a.nLast = nLast;
   a.grid = make_grid(d_kpsUn, d_cellStart, d_entries, bounds);

@@ -73,6 +73,27 @@ def search_by_projection_points(ex, frame, in_view, proj, proj_xr, level, view_c
     return nm.value, out[:n.value].copy(), rounds.value
 
 
+def search_by_projection_keyframe(ex, frame, kf_valid, uv, level, kf_angle, kf_desc, has_point=None, th=10.0,
+                                  orb_dist=100, check_orientation=True):
+    """ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (matcher.cc:
+    1810-1923) -> (nmatches, assigned[n], rounds)."""
+    kv = np.ascontiguousarray(kf_valid, np.uint8)
+    uvf = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
+    lv = np.ascontiguousarray(level, np.int32)
+    ka = np.ascontiguousarray(kf_angle, np.float32)
+    kd = np.ascontiguousarray(kf_desc, np.uint8).reshape(-1, 32)
+    assert len(uvf) == len(lv) == len(ka) == len(kd) == len(kv)
+    hp = None if has_point is None else np.ascontiguousarray((np.asarray(has_point) != 0).astype(np.uint8))
+    cap = ex.max_keypoints()
+    out = np.zeros(cap, np.int32)
+    n, nm, rounds = C.c_int32(), C.c_int32(), C.c_int32()
+    check(lib().orbx_search_by_projection_keyframe(
+        ex._h, int(frame), len(kv), ptr(kv), uvf.ctypes.data_as(_f32p), lv.ctypes.data_as(_i32p),
+        ka.ctypes.data_as(_f32p), ptr(kd), ptr(hp), float(th), int(orb_dist), int(bool(check_orientation)), ptr(out),
+        cap, C.byref(n), C.byref(nm), C.byref(rounds)), "orbx_search_by_projection_keyframe")
+    return nm.value, out[:n.value].copy(), rounds.value
+
+
 def search_by_bow(ex, frame, kf_valid, kf_angle, kf_desc, kf_node_ids, kf_node_start, kf_features, nnratio=0.7,
                   check_orientation=True):
     """ORBmatcher::SearchByBoW(pKF, F, ...) (matcher.cc:222-405) -> (nmatches, matches[n]).  The

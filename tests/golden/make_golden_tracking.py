@@ -66,7 +66,15 @@ def main():
     np_, pasg = O.search_by_projection_points(pt_in_view, pt_proj, pt_proj_xr, pt_level, pt_view_cos, dp2, pt_obs, un, db,
                                               u_right, state, bounds, cs, ent, sf, pt_th, pt_ratio)
     print("guided", np_, "map-point matches of", n2)
-    np.savez_compressed(os.path.join(HERE, "guided_376x240.npz"), pt_in_view=pt_in_view, pt_proj=pt_proj,
+    # relocalisation: the keypoints of frame a as a keyframe's map points (matcher.cc:1810-1923)
+    rng4 = np.random.default_rng(20)
+    kf_level = np.clip(ka["octave"] + rng4.integers(-1, 2, n_last), 0, PARAMS[2] - 1).astype(np.int32)
+    kf_has_point = (rng4.random(len(kb)) < 0.2).astype(np.uint8)
+    kf_n, kf_asg = O.search_by_projection_keyframe(valid, uv, kf_level, ka["angle"], da, un, db, kf_has_point, bounds,
+                                                   cs, ent, sf, 10.0, 64, True)
+    print("guided", kf_n, "keyframe projection matches")
+    np.savez_compressed(os.path.join(HERE, "guided_376x240.npz"), kf_level=kf_level, kf_has_point=kf_has_point,
+                        kf_th=10.0, kf_orb_dist=64, kf_nmatches=kf_n, kf_assigned=kf_asg, pt_in_view=pt_in_view, pt_proj=pt_proj,
                         pt_proj_xr=pt_proj_xr, pt_level=pt_level, pt_view_cos=pt_view_cos, pt_obs=pt_obs, pt_th=pt_th,
                         pt_ratio=pt_ratio, pt_nmatches=np_, pt_assigned=pasg, seed=SEED, shift=SHIFT, w=W, h=H,
                         params=np.array(PARAMS, np.float64), a_crc32=zlib.crc32(a.tobytes()),

@@ -192,6 +192,27 @@ int main(int argc, char** argv) {
     }
   }
 
+  step("search by projection from a keyframe");
+  {
+    const int nk = n[0];
+    std::vector<uint8_t> valid(nk, 1), has(cap);
+    std::vector<float> uv(2 * (size_t)nk), ang(nk);
+    std::vector<int32_t> lvl(nk), assigned(cap);
+    std::uniform_real_distribution<float> jitter(-6.f, 6.f);
+    for (int i = 0; i < nk; ++i) {
+      uv[2 * i] = kun[i].x + jitter(rng);
+      uv[2 * i + 1] = kun[i].y + jitter(rng);
+      ang[i] = kun[i].angle;
+      lvl[i] = kun[i].octave;
+    }
+    for (int i = 0; i < cap; ++i) has[i] = rng() % 5 == 0;
+    const std::vector<uint8_t> dk = perturbed(desc.data(), nk, 16, rng);
+    int nout = 0, nm = 0, rounds = 0;
+    CHECK(orbx_search_by_projection_keyframe(left, 0, nk, valid.data(), uv.data(), lvl.data(), ang.data(), dk.data(),
+                                             has.data(), 10.0f, 100, 1, assigned.data(), cap, &nout, &nm, &rounds));
+    fprintf(stderr, "race_driver:   %d matches in %d rounds\n", nm, rounds);
+  }
+
   step("search by projection of map points");
   {
     // three map points per keypoint of frame 0, each with its own jitter

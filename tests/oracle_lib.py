@@ -59,6 +59,8 @@ def lib():
             [C.c_void_p] * 4 + [C.c_float, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]
         L.orc_search_by_projection_points.argtypes = [C.c_void_p] * 7 + [C.c_int] + [C.c_void_p] * 4 + [C.c_int] + \
             [C.c_void_p] * 4 + [C.c_float, C.c_float, C.c_void_p]
+        L.orc_search_by_projection_keyframe.argtypes = [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] + \
+            [C.c_void_p] * 4 + [C.c_float, C.c_int, C.c_int, C.c_void_p]
         L.orc_search_by_bow.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_int] + \
             [C.c_void_p] * 3 + [C.c_float, C.c_int, C.c_void_p]
         _lib = L
@@ -331,6 +333,26 @@ def search_by_projection_points(in_view, proj, proj_xr, level, view_cos, pt_desc
     n = lib().orc_search_by_projection_points(_p(iv), _p(pj), _p(xr), _p(lv), _p(vc), _p(pd), _p(po), len(iv),
                                               _p(k), _p(d), _p(ur) if ur is not None else None, _p(st), len(k),
                                               _p(b), _p(cs), _p(ent), _p(sf), th, nnratio, _p(out))
+    return n, out[:len(k)]
+
+
+def search_by_projection_keyframe(kf_valid, uv, level, kf_angle, kf_desc, k, d, has_point, bounds, cs, ent,
+                                  scale_factors, th, orb_dist, check_orientation=True):
+    kv = np.ascontiguousarray(kf_valid, np.uint8)
+    uv = np.ascontiguousarray(uv, np.float32)
+    lv = np.ascontiguousarray(level, np.int32)
+    ka = np.ascontiguousarray(kf_angle, np.float32)
+    kd = np.ascontiguousarray(kf_desc, np.uint8)
+    k = np.ascontiguousarray(k, KP)
+    d = np.ascontiguousarray(d, np.uint8)
+    hp = np.ascontiguousarray(has_point, np.uint8)
+    ent = np.ascontiguousarray(ent if len(ent) else np.zeros(1), np.int32)
+    b = np.ascontiguousarray(bounds, np.float32)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    out = np.zeros(max(len(k), 1), np.int32)
+    n = lib().orc_search_by_projection_keyframe(_p(kv), _p(uv), _p(lv), _p(ka), _p(kd), len(kv), _p(k), _p(d), _p(hp),
+                                                len(k), _p(b), _p(cs), _p(ent), _p(sf), th, int(orb_dist),
+                                                int(check_orientation), _p(out))
     return n, out[:len(k)]
 
 

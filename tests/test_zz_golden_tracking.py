@@ -46,6 +46,11 @@ def test_oracle_reproduces_guided_golden(oracle):
                                                    bounds, cs, ent, np.array(eb.tables()["scale"], np.float32),
                                                    float(g["pt_th"]), float(g["pt_ratio"]))
     assert npm == int(g["pt_nmatches"]) and np.array_equal(pasg, g["pt_assigned"])
+    nk, kasg = oracle.search_by_projection_keyframe(g["valid"], g["uv"], g["kf_level"], ka["angle"], da, un, db,
+                                                    g["kf_has_point"], bounds, cs, ent,
+                                                    np.array(eb.tables()["scale"], np.float32), float(g["kf_th"]),
+                                                    int(g["kf_orb_dist"]), True)
+    assert nk == int(g["kf_nmatches"]) and np.array_equal(kasg, g["kf_assigned"])
 
 
 def test_oracle_reproduces_bow_golden(oracle):
@@ -82,6 +87,9 @@ def test_hip_reproduces_guided_golden():
                                                       g["pt_view_cos"], np.concatenate([da, da]), g["pt_obs"],
                                                       g["u_right"], g["state"], float(g["pt_th"]), float(g["pt_ratio"]))
     assert npm == int(g["pt_nmatches"]) and np.array_equal(pasg, g["pt_assigned"])
+    nk, kasg, _ = guided.search_by_projection_keyframe(ex, 0, g["valid"], g["uv"], g["kf_level"], ka["angle"], da,
+                                                       g["kf_has_point"], float(g["kf_th"]), int(g["kf_orb_dist"]), True)
+    assert nk == int(g["kf_nmatches"]) and np.array_equal(kasg, g["kf_assigned"])
 
 
 @pytest.mark.gpu

@@ -1,6 +1,7 @@
 """GPU parity of the local-map matcher, ORBmatcher::SearchByProjection(F, vpMapPoints, th, ...)
-(core/lib/ORB/matcher.cc:41-142, monocular / rectified case), against the CPU oracle's sequential
-loop: assignments and match counts identical.
+(core/lib/ORB/matcher.cc:41-142, monocular / rectified case), and of the relocalisation matcher,
+SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (:1810-1923), against the CPU
+oracle's sequential loops: assignments and match counts identical.
 
 Collected after the other GPU tests on purpose: this kernel is the newest code."""
 import numpy as np
@@ -91,3 +92,31 @@ def test_search_by_projection_points_empty_and_errors(oracle):
     with pytest.raises(OrbxError):            # no such frame
         guided.search_by_projection_points(exb, 1, np.ones(1, np.uint8), np.zeros((1, 2)), np.zeros(1), [0], [1.0],
                                            np.zeros((1, 32)), [1])
+
+
+@pytest.mark.parametrize("th,orb_dist,ori,taken_p", [(10.0, 100, True, 0.3), (3.0, 64, True, 0.0), (10.0, 64, False, 0.3),
+                                                     (25.0, 255, True, 0.1), (10.0, 0, True, 0.0)])
+def test_search_by_projection_keyframe_matches_oracle(oracle, th, orb_dist, ori, taken_p):
+    exb, ka, da, kb, db, bounds, cs, ent = two_frames()
+    rng = np.random.default_rng(21)
+    n = len(ka)
+    uv = np.stack([ka["x"] + 6 + rng.uniform(-3, 3, n), ka["y"] + rng.uniform(-3, 3, n)], 1).astype(np.float32)
+    uv[::17] += 700
+    level = np.clip(ka["octave"] + rng.integers(-1, 2, n), 0, 7).astype(np.int32)
+    valid = (rng.random(n) < 0.85).astype(np.uint8)
+    desc = da.copy()
+    flip = rng.random(n) < 0.5
+    desc[flip, 7] ^= 0x3C
+    has_point = (rng.random(len(kb)) < taken_p).astype(np.uint8)
+    sf = np.array(exb.GetScaleFactors(), np.float32)
+    want_n, want = oracle.search_by_projection_keyframe(valid, uv, level, ka["angle"], desc, kb, db, has_point, bounds,
+                                                        cs, ent, sf, th, orb_dist, ori)
+    nm, asg, rounds = guided.search_by_projection_keyframe(exb, 0, valid, uv, level, ka["angle"], desc,
+                                                           has_point if taken_p else None, th, orb_dist, ori)
+    assert nm == want_n and np.array_equal(asg, want), (th, orb_dist, ori)
+    assert 1 <= rounds <= 24, rounds
+    if orb_dist >= 64:
+        assert (asg >= 0).sum() > 100
+        assert not (has_point.astype(bool) & (asg != -1)).any()      # keypoints with a map point stay untouched
+    with pytest.raises(orbx.OrbxError):
+        guided.search_by_projection_keyframe(exb, 0, valid, uv, level, ka["angle"], desc, None, th, 256, ori)

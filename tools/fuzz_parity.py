@@ -199,6 +199,16 @@ def grid_and_matchers(rng, img, params):
                                                       use_state, th, fwd, bwd, 40.0, ori)
     assert n == want_n and np.array_equal(asg, want), "search by projection"
 
+    # the same queries as a keyframe's map points during relocalisation (matcher.cc:1810-1923)
+    has_point = (rng.random(len(k)) < rng.choice([0.0, 0.2])).astype(np.uint8)
+    lvl_kf = np.clip(ka["octave"] + rng.integers(-1, 2, n1), 0, params[2] - 1).astype(np.int32)
+    orb_dist = int(rng.choice([0, 50, 64, 100, 255]))
+    want_nk, want_k = oracle.search_by_projection_keyframe(valid, uv, lvl_kf, ka["angle"], da, un, d, has_point, b, cs,
+                                                           ent, sf, th, orb_dist, ori)
+    nk, asgk, _ = guided.search_by_projection_keyframe(ex, 0, valid, uv, lvl_kf, ka["angle"], da, has_point, th,
+                                                       orb_dist, ori)
+    assert nk == want_nk and np.array_equal(asgk, want_k), "search by projection from a keyframe"
+
     # the same keypoints as map points in view (several per keypoint)
     copies = int(rng.integers(1, 4))
     kp3, dp3 = np.concatenate([ka] * copies), np.concatenate([da] * copies)
