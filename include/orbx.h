@@ -218,6 +218,16 @@ int orbx_stereo_download(orbx_extractor* left, int frame, float* uright, float* 
 int orbx_stereo_match(orbx_extractor* left, orbx_extractor* right, float mbf, float mb,
                       float* uright, float* depth, int cap, int* n_out);
 
+/* Frame::ComputeStereoFromRGBD, core/src/Frame.cc:998-1016, for frames
+ * [0, n_frames) of the last extraction + grid call on ex (the undistorted x
+ * comes from the grid call): d_depth points at n_frames float images in device
+ * memory (height rows of stride_floats floats each, already scaled by the depth
+ * map factor as in the Frame constructor, Frame.cc:264-266).  Asynchronous on
+ * the handle's stream; results through orbx_stereo_results_device /
+ * orbx_stereo_download like a stereo pair's (l1_dist is -1). */
+int orbx_stereo_from_rgbd_batch_device(orbx_extractor* ex, int n_frames, const float* d_depth, int stride_floats,
+                                       float mbf);
+
 /* Results derived from an extraction (stereo association, frame grid, bag of
  * words) belong to the keypoints of that extraction: the next extraction on the
  * handle invalidates them, and their download / query calls return

@@ -1239,6 +1239,22 @@ int orc_search_by_projection_points(const uint8_t* inView, const float* proj, co
   return nmatches;
 }
 
+// Frame::ComputeStereoFromRGBD, core/src/Frame.cc:998-1016.  depthImg: H rows of stride floats.
+void orc_stereo_from_rgbd(const void* kps28, const void* kpsUn28, int n, const float* depthImg, int stride,
+                          float mbf, float* uRight, float* depth) {
+  const KeyPoint* K = (const KeyPoint*)kps28;
+  const KeyPoint* U = (const KeyPoint*)kpsUn28;
+  for (int i = 0; i < n; ++i) {
+    uRight[i] = -1; depth[i] = -1;
+    const float v = K[i].y, u = K[i].x;
+    const float d = depthImg[(size_t)(int)v * stride + (int)u];   // Mat::at<float>(v, u): indices truncate
+    if (d > 0) {
+      depth[i] = d;
+      uRight[i] = U[i].x - mbf / d;
+    }
+  }
+}
+
 // ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist), core/lib/ORB/
 // matcher.cc:1810-1923 (relocalisation), on flat arrays.  Per keypoint of the keyframe, the
 // caller's part (:1826-1853):

@@ -39,6 +39,9 @@ void launch_stereo(const Plan& hp, const Plan* dp, const uint8_t* pyrL, const ui
                    float mb, int* rowStart, int* entries, int* bandIdx, int* bandDist, int* sadDist,
                    float* uRight, float* depth, int nframes, hipStream_t s);
 int stereo_entries_per_keypoint(const Plan& hp);
+void launch_stereo_from_rgbd(const float* kps, const float* kpsUn, const int* n, int cap, const float* depthImg,
+                             size_t frameFloats, int stride, int W, int H, float mbf, float* uRight, float* depth,
+                             int* sadDist, int nframes, hipStream_t s);
 size_t frame_grid_lds_bytes(int cap);
 void launch_frame_grid(const float* d_kps, const int* d_n, int cap, const orbx_pinhole& cam, int distorted,
                        const float* bounds, float* d_kpsUn, int* d_cellStart, int* d_entries,
@@ -855,6 +858,37 @@ static bool same_geometry(const orbx_extractor* a, const orbx_extractor* b) {
          a->prm.scale_factor == b->prm.scale_factor;
 }
 
+// the per-keypoint buffers of a stereo association (allocated on first use, freed with the plan)
+static int ensure_stereo_buffers(orbx_extractor* ex) {
+  auto& last_hip_error = ex->last_hip_error;
+  const size_t slots = (size_t)ex->prm.max_batch * ex->hp.kp_cap;
+  if (!ex->d_stRowStart)
+    HIP_TRY(hipMalloc((void**)&ex->d_stRowStart, (size_t)ex->prm.max_batch * (ex->hp.lv[0].h + 1) * 4));
+  if (!ex->d_stBandIdx) HIP_TRY(hipMalloc((void**)&ex->d_stBandIdx, slots * 4));
+  if (!ex->d_stBandDist) HIP_TRY(hipMalloc((void**)&ex->d_stBandDist, slots * 4));
+  if (!ex->d_stSad) HIP_TRY(hipMalloc((void**)&ex->d_stSad, slots * 4));
+  if (!ex->d_stDepth) HIP_TRY(hipMalloc((void**)&ex->d_stDepth, slots * 4));
+  if (!ex->d_stURight) HIP_TRY(hipMalloc((void**)&ex->d_stURight, slots * 4));
+  return ORBX_OK;
+}
+
+int orbx_stereo_from_rgbd_batch_device(orbx_extractor* ex, int n_frames, const float* d_depth, int stride_floats,
+                                       float mbf) {
+  if (!ex || !ex->planned || !ex->d_kpsUn || n_frames <= 0 || !d_depth || stride_floats < ex->hp.W)
+    return ORBX_ERR_BAD_ARG;
+  if (n_frames > ex->gridFrames) return ORBX_ERR_BATCH;   // the undistorted keypoints come from the grid call
+  if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  auto& last_hip_error = ex->last_hip_error;
+  const int st = ensure_stereo_buffers(ex);
+  if (st != ORBX_OK) return st;
+  orbx::launch_stereo_from_rgbd(ex->d_kps, ex->d_kpsUn, ex->d_n, ex->hp.kp_cap, d_depth,
+                                (size_t)stride_floats * ex->hp.H, stride_floats, ex->hp.W, ex->hp.H, mbf,
+                                ex->d_stURight, ex->d_stDepth, ex->d_stSad, n_frames, ex->stream);
+  HIP_TRY(hipGetLastError());
+  ex->stereoFrames = n_frames;
+  return ORBX_OK;
+}
+
 int orbx_stereo_match_batch_device(orbx_extractor* left, orbx_extractor* right, int n_frames, float mbf,
                                    float mb) {
   if (!left || !right || left == right || n_frames <= 0 || !(mb > 0.f) || !(mbf > 0.f))
@@ -864,14 +898,9 @@ int orbx_stereo_match_batch_device(orbx_extractor* left, orbx_extractor* right, 
   orbx_extractor* ex = left;
   if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
   auto& last_hip_error = ex->last_hip_error;
-  if (!ex->d_stURight) {
-    const size_t slots = (size_t)ex->prm.max_batch * ex->hp.kp_cap;
-    HIP_TRY(hipMalloc((void**)&ex->d_stRowStart, (size_t)ex->prm.max_batch * (ex->hp.lv[0].h + 1) * 4));
-    HIP_TRY(hipMalloc((void**)&ex->d_stBandIdx, slots * 4));
-    HIP_TRY(hipMalloc((void**)&ex->d_stBandDist, slots * 4));
-    HIP_TRY(hipMalloc((void**)&ex->d_stSad, slots * 4));
-    HIP_TRY(hipMalloc((void**)&ex->d_stURight, slots * 4));
-    HIP_TRY(hipMalloc((void**)&ex->d_stDepth, slots * 4));
+  {
+    const int st = ensure_stereo_buffers(ex);
+    if (st != ORBX_OK) return st;
   }
   if (right->hp.kp_cap > ex->stRightCap) {
     HIP_TRY(hipStreamSynchronize(ex->stream));

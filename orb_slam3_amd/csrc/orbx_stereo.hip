@@ -286,4 +286,37 @@ void launch_stereo(const Plan& hp, const Plan* dp, const uint8_t* pyrL, const ui
   hipLaunchKernelGGL(k_stereo_outliers, dim3(nframes), dim3(256), 0, s, nL, capL, sadDist, uRight, depth);
 }
 
+// Frame::ComputeStereoFromRGBD, core/src/Frame.cc:998-1016: the depth image is read at the
+// keypoint's own (distorted) position, indices truncated as Mat::at<float>(float, float) does;
+// mvuRight comes from the undistorted x.
+__global__ __launch_bounds__(256) void k_stereo_from_rgbd(const SKP* __restrict__ kps, const SKP* __restrict__ kpsUn,
+                                                          const int* __restrict__ nP, int cap,
+                                                          const float* __restrict__ depthImg, size_t frameFloats,
+                                                          int stride, int W, int H, float mbf,
+                                                          float* __restrict__ uRight, float* __restrict__ depth,
+                                                          int* __restrict__ sadDist) {
+  const int f = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nP[f]) return;
+  const size_t o = (size_t)f * cap + i;
+  const SKP kp = kps[o];
+  const int u = min(max((int)kp.x, 0), W - 1), v = min(max((int)kp.y, 0), H - 1);
+  const float d = depthImg[(size_t)f * frameFloats + (size_t)v * stride + u];
+  float ur = -1.0f, dp = -1.0f;
+  if (d > 0) {
+    dp = d;
+    ur = __fsub_rn(kpsUn[o].x, __fdiv_rn(mbf, d));
+  }
+  uRight[o] = ur;
+  depth[o] = dp;
+  sadDist[o] = -1;
+}
+
+void launch_stereo_from_rgbd(const float* kps, const float* kpsUn, const int* n, int cap, const float* depthImg,
+                             size_t frameFloats, int stride, int W, int H, float mbf, float* uRight, float* depth,
+                             int* sadDist, int nframes, hipStream_t s) {
+  hipLaunchKernelGGL(k_stereo_from_rgbd, dim3((cap + 255) / 256, nframes), dim3(256), 0, s, (const SKP*)kps,
+                     (const SKP*)kpsUn, n, cap, depthImg, frameFloats, stride, W, H, mbf, uRight, depth, sadDist);
+}
+
 }  // namespace orbx

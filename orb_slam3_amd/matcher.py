@@ -65,6 +65,15 @@ def compute_stereo_matches_batch(ex_left, ex_right, n_frames, mbf, mb):
                                                float(mb)), "orbx_stereo_match_batch_device")
 
 
+def compute_stereo_from_rgbd_batch(ex, n_frames, d_depth_ptr, stride_floats, mbf):
+    """Frame::ComputeStereoFromRGBD (core/src/Frame.cc:998-1016) for frames [0, n_frames) of the
+    last extraction + grid.frame_grid_batch on ex; d_depth_ptr = device address of the float depth
+    images.  Asynchronous; fetch results with stereo_download()."""
+    check(lib().orbx_stereo_from_rgbd_batch_device(ex._h, int(n_frames), C.c_void_p(int(d_depth_ptr)),
+                                                   int(stride_floats), float(mbf)),
+          "orbx_stereo_from_rgbd_batch_device")
+
+
 def stereo_download(ex_left, frame, with_l1=False):
     """(mvuRight, mvDepth[, L1 distance]) of one frame of the last stereo call."""
     cap = ex_left.max_keypoints()

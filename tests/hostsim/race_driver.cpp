@@ -143,6 +143,18 @@ int main(int argc, char** argv) {
   CHECK(orbx_frame_grid_batch_device(left, NF, nullptr, bounds));
   CHECK(orbx_frame_grid_download(left, 0, kun.data(), cstart.data(), centries.data(), cap, &nn));
 
+  step("depth association from a depth image");
+  {
+    std::vector<float> dimg((size_t)NF * W * H);
+    for (auto& v : dimg) v = (rng() % 5 == 0) ? 0.0f : 0.5f + (float)(rng() % 1000) * 0.01f;
+    void* dd;
+    hipMalloc(&dd, dimg.size() * 4);
+    hipMemcpy(dd, dimg.data(), dimg.size() * 4, 1);
+    CHECK(orbx_stereo_from_rgbd_batch_device(left, NF, (const float*)dd, W, 40.0f));
+    CHECK(orbx_stereo_download(left, 1, uright.data(), depth.data(), l1.data(), cap, &nn));
+    hipFree(dd);
+  }
+
   step("window queries on the grid");
   {
     const int nq = 300, pq = 64;

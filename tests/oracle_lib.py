@@ -59,6 +59,9 @@ def lib():
             [C.c_void_p] * 4 + [C.c_float, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]
         L.orc_search_by_projection_points.argtypes = [C.c_void_p] * 7 + [C.c_int] + [C.c_void_p] * 4 + [C.c_int] + \
             [C.c_void_p] * 4 + [C.c_float, C.c_float, C.c_void_p]
+        L.orc_stereo_from_rgbd.restype = None
+        L.orc_stereo_from_rgbd.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p,
+                                           C.c_void_p]
         L.orc_search_by_projection_keyframe.argtypes = [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] + \
             [C.c_void_p] * 4 + [C.c_float, C.c_int, C.c_int, C.c_void_p]
         L.orc_search_by_bow.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_int] + \
@@ -334,6 +337,16 @@ def search_by_projection_points(in_view, proj, proj_xr, level, view_cos, pt_desc
                                               _p(k), _p(d), _p(ur) if ur is not None else None, _p(st), len(k),
                                               _p(b), _p(cs), _p(ent), _p(sf), th, nnratio, _p(out))
     return n, out[:len(k)]
+
+
+def stereo_from_rgbd(kps, kps_un, depth_img, mbf):
+    k = np.ascontiguousarray(kps, KP)
+    u = np.ascontiguousarray(kps_un, KP)
+    dimg = np.ascontiguousarray(depth_img, np.float32)
+    ur = np.zeros(max(len(k), 1), np.float32)
+    dp = np.zeros(max(len(k), 1), np.float32)
+    lib().orc_stereo_from_rgbd(_p(k), _p(u), len(k), _p(dimg), dimg.shape[1], mbf, _p(ur), _p(dp))
+    return ur[:len(k)], dp[:len(k)]
 
 
 def search_by_projection_keyframe(kf_valid, uv, level, kf_angle, kf_desc, k, d, has_point, bounds, cs, ent,
