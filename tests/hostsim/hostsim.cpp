@@ -10,7 +10,8 @@
 //    the rear guard.
 //  * threads of a workgroup: fibers switched by a few instructions of assembly; a fiber runs
 //    until its next cross-lane operation or barrier.  Workgroups of a launch are spread over
-//    HOSTSIM_THREADS worker threads (default: the machine's cores, at most 8).
+//    HOSTSIM_THREADS worker threads (default: the machine's cores, at most 8).  HOSTSIM_ORDER =
+//    reverse | shuffle:<seed> changes the order in which the scheduler visits the threads.
 #include <hip/hip_runtime.h>
 
 #include <execinfo.h>
@@ -366,10 +367,31 @@ static void run_block(Block* b, const char* name, uint3 bid, dim3 grid, dim3 blo
   // HOSTSIM_ORDER=reverse runs the threads of a workgroup from the last to the first: code whose
   // result depends on which thread gets to a point first (a missing barrier) changes its output
   static const bool reverseOrder = [] { const char* e = getenv("HOSTSIM_ORDER"); return e && !strcmp(e, "reverse"); }();
+  // HOSTSIM_ORDER=shuffle:<seed>: a fresh pseudo-random order of the waves, and of the lanes
+  // inside each wave, for every sweep of the scheduler
+  static const long shuffleSeed = [] {
+    const char* e = getenv("HOSTSIM_ORDER");
+    return (e && !strncmp(e, "shuffle:", 8)) ? atol(e + 8) + 1 : 0L;
+  }();
+  uint64_t rs = (uint64_t)shuffleSeed * 0x9E3779B97F4A7C15ull + bid.x * 1315423911ull + bid.y * 2654435761ull;
+  auto rnd = [&rs]() { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; return rs; };
+  std::vector<int> order;
+  if (shuffleSeed) order.resize(nt);
   while (b->alive > 0) {
     bool progressed = false;
+    if (shuffleSeed) {
+      std::vector<int> waves(b->nwaves);
+      for (int w = 0; w < b->nwaves; ++w) waves[w] = w;
+      for (int w = b->nwaves - 1; w > 0; --w) std::swap(waves[w], waves[rnd() % (w + 1)]);
+      int at = 0;
+      for (int w : waves) {
+        const int first = at, cnt = std::min(64, nt - 64 * w);
+        for (int l = 0; l < cnt; ++l) order[at++] = 64 * w + l;
+        for (int l = cnt - 1; l > 0; --l) std::swap(order[first + l], order[first + rnd() % (l + 1)]);
+      }
+    }
     for (int k = 0; k < nt; ++k) {
-      const int i = reverseOrder ? nt - 1 - k : k;
+      const int i = shuffleSeed ? order[k] : (reverseOrder ? nt - 1 - k : k);
       Lane& l = b->lanes[i];
       if (l.done) continue;
       if (l.waitOn && *l.waitOn == l.waitVal) continue;
