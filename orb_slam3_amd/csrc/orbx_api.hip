@@ -1066,6 +1066,27 @@ struct Carver {
   size_t add(size_t bytes) { const size_t at = total; total += (bytes + 255) / 256 * 256; return at; }
 };
 const int kGuidedMaxQueries = 1 << 20;
+
+// The host arrays of one call, packed by the CPU into one block and moved with one transfer
+// (every separate copy from pageable memory costs a round trip through the driver).  The block
+// must stay alive until the stream has been synchronised.
+struct PackedUpload {
+  std::vector<uint8_t> host;
+  size_t lo = (size_t)-1, hi = 0;
+  bool init(size_t bytes) noexcept {
+    try { host.assign(bytes, 0); return true; } catch (...) { return false; }
+  }
+  void add(size_t off, const void* src, size_t bytes) {
+    if (!bytes || off + bytes > host.size()) return;
+    std::memcpy(host.data() + off, src, bytes);
+    lo = std::min(lo, off);
+    hi = std::max(hi, off + bytes);
+  }
+  hipError_t send(uint8_t* d, hipStream_t s) const {
+    if (hi <= lo) return hipSuccess;
+    return hipMemcpyAsync(d + lo, host.data() + lo, hi - lo, hipMemcpyHostToDevice, s);
+  }
+};
 }  // namespace
 
 namespace {
@@ -1110,13 +1131,14 @@ int search_by_projection(orbx_extractor* cur, int frame, int n_last, const uint8
   uint8_t* d = nullptr;
   hipError_t e = hipMallocAsync((void**)&d, c.total, s);
   if (e != hipSuccess) { last_hip_error = e; return ORBX_ERR_HIP; }
-  auto up = [&](size_t off, const void* src, size_t bytes) {
-    if (e == hipSuccess) e = hipMemcpyAsync(d + off, src, bytes, hipMemcpyHostToDevice, s);
-  };
+  PackedUpload pk;
+  if (!pk.init(oWork)) { (void)hipFreeAsync(d, s); return ORBX_ERR_UNSUPPORTED; }
+  auto up = [&](size_t off, const void* src, size_t bytes) { pk.add(off, src, bytes); };
   up(oValid, last_valid, nl); up(oUv, uv, nl * 8); up(oInvz, invz, nl * 4); up(oOct, last_octave, nl * 4);
   up(oAng, last_angle, nl * 4); up(oDesc, last_desc, nl * 32); up(oObs, last_obs, nl);
   if (u_right) up(oUr, u_right, nn * 4);
   if (state) up(oState, state, nn);
+  e = pk.send(d, s);
   int sum[2] = {0, 0};
   if (e == hipSuccess) {
     const size_t base = (size_t)frame * ex->hp.kp_cap;
@@ -1131,7 +1153,10 @@ int search_by_projection(orbx_extractor* cur, int frame, int n_last, const uint8
   }
   if (e == hipSuccess) e = hipMemcpyAsync(assigned, d + oAsg, nn * 4, hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) e = hipMemcpyAsync(sum, d + oSum, 8, hipMemcpyDeviceToHost, s);
-  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  {   // also after an error: the packed host block must outlive whatever was enqueued
+    const hipError_t es = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = es;
+  }
   (void)hipFreeAsync(d, s);
   if (e != hipSuccess) { last_hip_error = e; return ORBX_ERR_HIP; }
   *nmatches = sum[0];
@@ -1208,13 +1233,14 @@ int orbx_search_by_projection_points(orbx_extractor* f, int frame, int n_points,
   uint8_t* d = nullptr;
   hipError_t e = hipMallocAsync((void**)&d, c.total, s);
   if (e != hipSuccess) { last_hip_error = e; return ORBX_ERR_HIP; }
-  auto up = [&](size_t off, const void* src, size_t bytes) {
-    if (e == hipSuccess) e = hipMemcpyAsync(d + off, src, bytes, hipMemcpyHostToDevice, s);
-  };
+  PackedUpload pk;
+  if (!pk.init(oWork)) { (void)hipFreeAsync(d, s); return ORBX_ERR_UNSUPPORTED; }
+  auto up = [&](size_t off, const void* src, size_t bytes) { pk.add(off, src, bytes); };
   up(oView, in_view, np); up(oProj, proj, np * 8); up(oXr, proj_xr, np * 4); up(oLvl, level, np * 4);
   up(oCos, view_cos, np * 4); up(oDesc, desc, np * 32); up(oObs, obs, np);
   if (u_right) up(oUr, u_right, nn * 4);
   if (state) up(oState, state, nn);
+  e = pk.send(d, s);
   int sum[2] = {0, 0};
   if (e == hipSuccess) {
     const size_t base = (size_t)frame * ex->hp.kp_cap;
@@ -1228,7 +1254,10 @@ int orbx_search_by_projection_points(orbx_extractor* f, int frame, int n_points,
   }
   if (e == hipSuccess) e = hipMemcpyAsync(assigned, d + oAsg, nn * 4, hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) e = hipMemcpyAsync(sum, d + oSum, 8, hipMemcpyDeviceToHost, s);
-  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  {   // also after an error: the packed host block must outlive whatever was enqueued
+    const hipError_t es = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = es;
+  }
   (void)hipFreeAsync(d, s);
   if (e != hipSuccess) { last_hip_error = e; return ORBX_ERR_HIP; }
   *nmatches = sum[0];
@@ -1260,9 +1289,10 @@ int orbx_search_for_initialization(orbx_extractor* f2, int frame2, int n1, const
   uint8_t* d = nullptr;
   hipError_t e = hipMallocAsync((void**)&d, c.total, s);
   if (e != hipSuccess) { last_hip_error = e; return ORBX_ERR_HIP; }
-  if (e == hipSuccess) e = hipMemcpyAsync(d + oK1, kps1_un, a1 * 28, hipMemcpyHostToDevice, s);
-  if (e == hipSuccess) e = hipMemcpyAsync(d + oD1, desc1, a1 * 32, hipMemcpyHostToDevice, s);
-  if (e == hipSuccess) e = hipMemcpyAsync(d + oPm, prev_matched, a1 * 8, hipMemcpyHostToDevice, s);
+  PackedUpload pk;
+  if (!pk.init(oWork)) { (void)hipFreeAsync(d, s); return ORBX_ERR_UNSUPPORTED; }
+  pk.add(oK1, kps1_un, a1 * 28); pk.add(oD1, desc1, a1 * 32); pk.add(oPm, prev_matched, a1 * 8);
+  e = pk.send(d, s);
   int sum[2] = {0, 0};
   if (e == hipSuccess) {
     const size_t base = (size_t)frame2 * ex->hp.kp_cap;
@@ -1276,7 +1306,10 @@ int orbx_search_for_initialization(orbx_extractor* f2, int frame2, int n1, const
   if (e == hipSuccess) e = hipMemcpyAsync(matches12, d + oM12, a1 * 4, hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) e = hipMemcpyAsync(prev_matched, d + oPm, a1 * 8, hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) e = hipMemcpyAsync(sum, d + oSum, 8, hipMemcpyDeviceToHost, s);
-  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  {   // also after an error: the packed host block must outlive whatever was enqueued
+    const hipError_t es = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = es;
+  }
   (void)hipFreeAsync(d, s);
   if (e != hipSuccess) { last_hip_error = e; return ORBX_ERR_HIP; }
   *nmatches = sum[0];
@@ -1391,13 +1424,14 @@ int orbx_search_by_bow(orbx_extractor* f, int frame, int n_kf, const uint8_t* kf
   uint8_t* d = nullptr;
   hipError_t e = hipMallocAsync((void**)&d, c.total, s);
   if (e != hipSuccess) { last_hip_error = e; return ORBX_ERR_HIP; }
-  auto up = [&](size_t off, const void* src, size_t bytes) {
-    if (e == hipSuccess && bytes) e = hipMemcpyAsync(d + off, src, bytes, hipMemcpyHostToDevice, s);
-  };
+  PackedUpload pk;
+  if (!pk.init(oM)) { (void)hipFreeAsync(d, s); return ORBX_ERR_UNSUPPORTED; }
+  auto up = [&](size_t off, const void* src, size_t bytes) { pk.add(off, src, bytes); };
   up(oValid, kf_valid, (size_t)n_kf); up(oAng, kf_angle, (size_t)n_kf * 4); up(oDesc, kf_desc, (size_t)n_kf * 32);
   up(oNode, kf_node_ids, (size_t)n_kf_nodes * 4);
   if (n_kf_nodes > 0) up(oStart, kf_node_start, ((size_t)n_kf_nodes + 1) * 4);
   up(oFeat, kf_features, (size_t)nFeat * 4);
+  e = pk.send(d, s);
   int sum[2] = {0, 0};
   if (e == hipSuccess) {
     const size_t base = (size_t)frame * kc;
@@ -1411,7 +1445,10 @@ int orbx_search_by_bow(orbx_extractor* f, int frame, int n_kf, const uint8_t* kf
   }
   if (e == hipSuccess) e = hipMemcpyAsync(matches, d + oM, (size_t)n * 4, hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) e = hipMemcpyAsync(sum, d + oSum, 4, hipMemcpyDeviceToHost, s);
-  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  {   // also after an error: the packed host block must outlive whatever was enqueued
+    const hipError_t es = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = es;
+  }
   (void)hipFreeAsync(d, s);
   if (e != hipSuccess) { last_hip_error = e; return ORBX_ERR_HIP; }
   *nmatches = sum[0];
