@@ -218,6 +218,18 @@ int orbx_stereo_download(orbx_extractor* left, int frame, float* uright, float* 
 int orbx_stereo_match(orbx_extractor* left, orbx_extractor* right, float mbf, float mb,
                       float* uright, float* depth, int cap, int* n_out);
 
+/* The descriptor search of Frame::ComputeStereoFishEyeMatches, core/src/Frame.cc:
+ * 1157-1185, on two device-resident extractions made with the cameras' lapping
+ * areas: BFmatcher.knnMatch(stereoDescLeft, stereoDescRight, matches, 2) (:1177)
+ * with stereoDescLeft = rows [monoLeft, Nleft) of the left frame's descriptors
+ * and stereoDescRight = rows [monoRight, Nright) of the right one (:1159-1165),
+ * mono* being the two operator() return values.  idx / dist hold cap*2 entries
+ * in the layout of orbx_knn2; idx values are trainIdx (relative to monoRight).
+ * *n_query = Nleft - monoLeft (ORBX_ERR_CAPACITY if above cap), *n_train =
+ * Nright - monoRight; any of the four outputs may be NULL.  Blocks. */
+int orbx_lapping_knn2(orbx_extractor* left, orbx_extractor* right, int frame, uint32_t* idx, uint16_t* dist,
+                      int cap, int* n_query, int* mono_left, int* n_train, int* mono_right);
+
 /* Frame::ComputeStereoFromRGBD, core/src/Frame.cc:998-1016, for frames
  * [0, n_frames) of the last extraction + grid call on ex (the undistorted x
  * comes from the grid call): d_depth points at n_frames float images in device

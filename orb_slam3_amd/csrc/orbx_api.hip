@@ -964,6 +964,55 @@ int orbx_stereo_match(orbx_extractor* left, orbx_extractor* right, float mbf, fl
   return orbx_stereo_download(left, 0, uright, depth, nullptr, cap, n_out);
 }
 
+int orbx_lapping_knn2(orbx_extractor* left, orbx_extractor* right, int frame, uint32_t* idx, uint16_t* dist,
+                      int cap, int* n_query, int* mono_left, int* n_train, int* mono_right) {
+  if (!left || !right || left == right || !left->planned || !right->planned || left->device != right->device ||
+      frame < 0 || frame >= left->lastFrames || frame >= right->lastFrames || cap < 0)
+    return ORBX_ERR_BAD_ARG;
+  orbx_extractor* ex = left;
+  if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  auto& last_hip_error = ex->last_hip_error;
+  hipStream_t s = ex->stream;
+  if (!ex->evStereo) HIP_TRY(hipEventCreateWithFlags(&ex->evStereo, hipEventDisableTiming));
+  // the right extraction runs on its own stream: order this work after it
+  HIP_TRY(hipEventRecord(ex->evStereo, right->stream));
+  HIP_TRY(hipStreamWaitEvent(s, ex->evStereo, 0));
+  int h[4] = {0, 0, 0, 0};   // Nleft, monoLeft, Nright, monoRight
+  HIP_TRY(hipMemcpyAsync(&h[0], left->d_n + frame, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(&h[1], left->d_mono + frame, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(&h[2], right->d_n + frame, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(&h[3], right->d_mono + frame, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  const int nq = h[0] - h[1], nt = h[2] - h[3];
+  if (n_query) *n_query = nq;
+  if (mono_left) *mono_left = h[1];
+  if (n_train) *n_train = nt;
+  if (mono_right) *mono_right = h[3];
+  if (nq < 0 || nt < 0) return ORBX_ERR_BAD_ARG;
+  if (nq > cap) return ORBX_ERR_CAPACITY;
+  if (nq == 0) return ORBX_OK;
+  if (!idx || !dist) return ORBX_ERR_BAD_ARG;
+  uint8_t* d = nullptr;
+  const size_t oDist = ((size_t)nq * 8 + 255) / 256 * 256;
+  hipError_t e = hipMallocAsync((void**)&d, oDist + (size_t)nq * 4, s);
+  if (e != hipSuccess) { last_hip_error = e; return ORBX_ERR_HIP; }
+  const uint8_t* q = left->d_desc + ((size_t)frame * left->hp.kp_cap + h[1]) * 32;
+  const uint8_t* t = right->d_desc + ((size_t)frame * right->hp.kp_cap + h[3]) * 32;
+  int st = orbx_knn2_device(q, nq, t, nt, 0, (uint32_t*)d, (uint16_t*)(d + oDist), (void*)s);
+  if (st == ORBX_OK) {
+    e = hipMemcpyAsync(idx, d, (size_t)nq * 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(dist, d + oDist, (size_t)nq * 4, hipMemcpyDeviceToHost, s);
+  }
+  {
+    const hipError_t es = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = es;
+  }
+  (void)hipFreeAsync(d, s);
+  if (st != ORBX_OK) return st;
+  if (e != hipSuccess) { last_hip_error = e; return ORBX_ERR_HIP; }
+  return ORBX_OK;
+}
+
 // ---- frame grid on a device-resident extraction -----------------------------------------------
 #define ORBX_GRID_CELLS (64 * 48)
 

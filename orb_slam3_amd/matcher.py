@@ -65,6 +65,19 @@ def compute_stereo_matches_batch(ex_left, ex_right, n_frames, mbf, mb):
                                                float(mb)), "orbx_stereo_match_batch_device")
 
 
+def lapping_knn_match2(ex_left, ex_right, frame=0):
+    """The knnMatch of Frame::ComputeStereoFishEyeMatches (core/src/Frame.cc:1159-1177) on two
+    device-resident extractions: 2-NN of the left lapping-area descriptors against the right ones.
+    -> (idx[nq, 2], dist[nq, 2], mono_left, mono_right); idx are trainIdx (relative to mono_right)."""
+    cap = ex_left.max_keypoints()
+    idx = np.empty((cap, 2), np.uint32)
+    dist = np.empty((cap, 2), np.uint16)
+    nq, ml, nt, mr = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    check(lib().orbx_lapping_knn2(ex_left._h, ex_right._h, int(frame), ptr(idx), ptr(dist), cap, C.byref(nq),
+                                  C.byref(ml), C.byref(nt), C.byref(mr)), "orbx_lapping_knn2")
+    return idx[:nq.value].copy(), dist[:nq.value].copy(), ml.value, mr.value
+
+
 def compute_stereo_from_rgbd_batch(ex, n_frames, d_depth_ptr, stride_floats, mbf):
     """Frame::ComputeStereoFromRGBD (core/src/Frame.cc:998-1016) for frames [0, n_frames) of the
     last extraction + grid.frame_grid_batch on ex; d_depth_ptr = device address of the float depth

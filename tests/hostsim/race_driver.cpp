@@ -115,6 +115,14 @@ int main(int argc, char** argv) {
   CHECK(orbx_extract_batch(right, NF, pr, W, H, W, 0, 0, kpsR.data(), descR.data(), cap, nR, monoR));
   fprintf(stderr, "race_driver: keypoints %d %d | %d %d\n", n[0], n[1], nR[0], nR[1]);
 
+  step("lapping-area 2-NN on the two extractions");
+  {
+    std::vector<uint32_t> li((size_t)cap * 2);
+    std::vector<uint16_t> ld((size_t)cap * 2);
+    int nq = 0, ml = 0, nt = 0, mr = 0;
+    CHECK(orbx_lapping_knn2(left, right, 1, li.data(), ld.data(), cap, &nq, &ml, &nt, &mr));
+  }
+
   step("stereo association");
   CHECK(orbx_stereo_match_batch_device(left, right, NF, 40.0f, 0.1f));
   std::vector<float> uright(cap), depth(cap);
