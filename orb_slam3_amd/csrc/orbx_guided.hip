@@ -28,6 +28,7 @@
 // GUIDED_CACHE candidates walk again).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/orbx.h"
 #include "orbx_plan.h"
@@ -163,11 +164,13 @@ struct ProjectionArgs {
   // results
   int* assigned;           // n
   int* summary;            // [0] nmatches, [1] rounds
+  int gathered;            // the candidate lists were filled by a gather launch before this one
 };
 
 // choice of last-frame keypoint i given the closing times of the previous round
 // (matcher.cc:1607-1690): the keypoint it matches, or -1.  store: remember the candidates.
-__device__ int projection_choice(const ProjectionArgs& a, int i, const int* closedAt, bool store) {
+// decide = false only walks and stores (closedAt is not read).
+__device__ int projection_choice(const ProjectionArgs& a, int i, const int* closedAt, bool store, bool decide = true) {
   if (store) a.candCount[i] = 0;
   if (!a.lastValid[i]) return -1;
   const float invzc = a.invz[i];
@@ -201,7 +204,7 @@ __device__ int projection_choice(const ProjectionArgs& a, int i, const int* clos
     }
     // closed: the keypoint holds a map point with observations, from the start (-1) or
     // since an earlier query put one there (matcher.cc:1663-1666)
-    if (coherent_load(&closedAt[i2]) < i) return;
+    if (!decide || coherent_load(&closedAt[i2]) < i) return;
     if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
   });
   if (store) a.candCount[i] = k <= GUIDED_CACHE ? k : -1;
@@ -218,6 +221,15 @@ __device__ int projection_choice_cached(const ProjectionArgs& a, int i, const in
     if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
   }
   return bestDist <= a.maxDist ? bestIdx2 : -1;
+}
+
+// The window walks of all queries, spread over the chip: they do not depend on each other, and
+// one workgroup (one CU) would take them a few queries per thread, one dependent load after the
+// other.  The rounds kernel then starts from the remembered lists.
+#define GATHER_THREADS 64
+__global__ __launch_bounds__(GATHER_THREADS) void k_gather_projection(ProjectionArgs a) {
+  const int i = blockIdx.x * GATHER_THREADS + threadIdx.x;
+  if (i < a.nLast) (void)projection_choice(a, i, nullptr, true, false);
 }
 
 __global__ __launch_bounds__(GUIDED_THREADS) void k_search_by_projection_last(ProjectionArgs a) {
@@ -241,7 +253,7 @@ __global__ __launch_bounds__(GUIDED_THREADS) void k_search_by_projection_last(Pr
     int changed = 0;
     for (int i = tid; i < a.nLast; i += GUIDED_THREADS) {
       int c;
-      if (rounds == 0) {
+      if (rounds == 0 && !a.gathered) {
         c = projection_choice(a, i, bPrev, true);
       } else {
         const int cnt = a.candCount[i];
@@ -324,6 +336,7 @@ struct PointsArgs {
   // results
   int* assigned;           // n
   int* summary;            // [0] nmatches, [1] rounds
+  int gathered;            // as in ProjectionArgs
 };
 
 // best and second-best candidate with their pyramid levels, and the acceptance rule of
@@ -349,7 +362,7 @@ struct BestTwo {
 
 // choice of map point i given the closing times of the previous round.  store: remember the
 // candidates.
-__device__ int points_choice(const PointsArgs& a, int i, const int* closedAt, bool store) {
+__device__ int points_choice(const PointsArgs& a, int i, const int* closedAt, bool store, bool decide = true) {
   if (store) a.candCount[i] = 0;
   if (!a.inView[i]) return -1;
   const int nPredictedLevel = a.level[i];
@@ -378,7 +391,7 @@ __device__ int points_choice(const PointsArgs& a, int i, const int* closedAt, bo
         a.cand[(size_t)k * a.nPts + i] = ((uint32_t)dist << 20) | ((uint32_t)octave << 16) | (uint32_t)i2;
       ++k;
     }
-    if (coherent_load(&closedAt[i2]) < i) return;   // holds a map point with observations (:89-91)
+    if (!decide || coherent_load(&closedAt[i2]) < i) return;   // holds a map point with observations (:89-91)
     b.consider(i2, dist, octave);
   });
   if (store) a.candCount[i] = k <= GUIDED_CACHE ? k : -1;
@@ -394,6 +407,11 @@ __device__ int points_choice_cached(const PointsArgs& a, int i, const int* close
     b.consider(i2, (int)(e >> 20), (int)((e >> 16) & 0xFu));
   }
   return b.accepted(a.nnratio);
+}
+
+__global__ __launch_bounds__(GATHER_THREADS) void k_gather_points(PointsArgs a) {
+  const int i = blockIdx.x * GATHER_THREADS + threadIdx.x;
+  if (i < a.nPts) (void)points_choice(a, i, nullptr, true, false);
 }
 
 __global__ __launch_bounds__(GUIDED_THREADS) void k_search_by_projection_points(PointsArgs a) {
@@ -414,7 +432,7 @@ __global__ __launch_bounds__(GUIDED_THREADS) void k_search_by_projection_points(
     int changed = 0;
     for (int i = tid; i < a.nPts; i += GUIDED_THREADS) {
       int c;
-      if (rounds == 0) {
+      if (rounds == 0 && !a.gathered) {
         c = points_choice(a, i, bPrev, true);
       } else {
         const int cnt = a.candCount[i];
@@ -473,6 +491,7 @@ struct InitArgs {
   // results
   int* matches12;          // n1
   int* summary;            // [0] nmatches, [1] rounds
+  int gathered;            // as in ProjectionArgs
 };
 
 // vMatchedDistance[i2] as query i1 meets it: the smallest distance accepted by an earlier query
@@ -484,7 +503,8 @@ __device__ __forceinline__ int init_seen(const InitArgs& a, int i1, int i2, cons
 }
 
 // claim of query i1 given the claims of the previous round (matcher.cc:638-704).
-// mode 0: walk the window and remember the candidates; 1: walk only; 2: use the remembered ones.
+// mode 0: walk the window and remember the candidates; 1: walk only; 2: use the remembered ones;
+// 3: walk and remember without deciding (the claims are not read).
 __device__ void init_choice(const InitArgs& a, int i1, const int* claimDistPrev, int mode, int* kpOut, int* distOut) {
   *kpOut = -1;
   *distOut = 0x7fffffff;
@@ -501,7 +521,8 @@ __device__ void init_choice(const InitArgs& a, int i1, const int* claimDistPrev,
       consider((int)(e & 0xFFFFu), (int)(e >> 16));
     }
   } else {
-    if (mode == 0) a.candCount[i1] = 0;
+    const bool store = mode == 0 || mode == 3;
+    if (store) a.candCount[i1] = 0;
     const GKP kp1 = a.K1[i1];
     const int level1 = kp1.octave;
     if (level1 > 0) return;
@@ -511,18 +532,24 @@ __device__ void init_choice(const InitArgs& a, int i1, const int* claimDistPrev,
     int k = 0;
     for_each_in_area(a.grid, a.prevMatched[2 * i1], a.prevMatched[2 * i1 + 1], a.window, level1, level1, [&](int i2) {
       const int dist = hamming_reg(d1, a.desc2 + (size_t)i2 * 8);
-      if (mode == 0) {
+      if (store) {
         if (k < GUIDED_CACHE) a.cand[(size_t)k * a.n1 + i1] = ((uint32_t)dist << 16) | (uint32_t)i2;
         ++k;
       }
-      consider(i2, dist);
+      if (mode != 3) consider(i2, dist);
     });
-    if (mode == 0) a.candCount[i1] = k <= GUIDED_CACHE ? k : -1;
+    if (store) a.candCount[i1] = k <= GUIDED_CACHE ? k : -1;
   }
   if (bestDist <= TH_LOW && (float)bestDist < __fmul_rn((float)bestDist2, a.nnratio)) {
     *kpOut = bestIdx2;
     *distOut = bestDist;
   }
+}
+
+__global__ __launch_bounds__(GATHER_THREADS) void k_gather_init(InitArgs a) {
+  const int i = blockIdx.x * GATHER_THREADS + threadIdx.x;
+  int c, d;
+  if (i < a.n1) init_choice(a, i, nullptr, 3, &c, &d);
 }
 
 __global__ __launch_bounds__(GUIDED_THREADS) void k_search_for_initialization(InitArgs a) {
@@ -550,7 +577,7 @@ __global__ __launch_bounds__(GUIDED_THREADS) void k_search_for_initialization(In
     int changed = 0;
     for (int i = tid; i < a.n1; i += GUIDED_THREADS) {
       int c, d;
-      init_choice(a, i, dPrev, rounds == 0 ? 0 : (a.candCount[i] >= 0 ? 2 : 1), &c, &d);
+      init_choice(a, i, dPrev, (rounds == 0 && !a.gathered) ? 0 : (a.candCount[i] >= 0 ? 2 : 1), &c, &d);
       cNew[i] = c;
       dNew[i] = d;
       changed |= (c != cPrev[i]) ? 1 : 0;
@@ -729,6 +756,18 @@ static GridView make_grid(const float* d_kpsUn, const int* d_cellStart, const in
   return g;
 }
 
+// Whether the window walks get a launch of their own (ORBX_GUIDED_GATHER=0 / 1 forces it off /
+// on; results are the same either way): worth a second launch once the queries outnumber what a
+// few waves of one CU would walk anyway.
+static int gather_first(int nQueries) {
+  static const int forced = [] {
+    const char* e = getenv("ORBX_GUIDED_GATHER");
+    return e ? (atoi(e) != 0 ? 1 : 0) : -1;
+  }();
+  if (forced >= 0) return forced;
+  return nQueries >= 256 ? 1 : 0;
+}
+
 // work memory either launcher needs beyond its inputs and outputs, in ints
 size_t projection_work_ints(int nLast, int n) { return (3 + GUIDED_CACHE) * (size_t)nLast + 2 * (size_t)n; }
 size_t init_work_ints(int n1, int n2) { return (6 + GUIDED_CACHE) * (size_t)n1 + (size_t)n2; }
@@ -754,6 +793,10 @@ void launch_search_by_projection_last(const uint8_t* d_lastValid, const float* d
   a.candCount = a.closedAt[1] + n;
   a.cand = (uint32_t*)(a.candCount + nLast);
   a.assigned = d_assigned; a.summary = d_summary;
+  a.gathered = gather_first(nLast);
+  if (a.gathered)
+    hipLaunchKernelGGL(k_gather_projection, dim3((nLast + GATHER_THREADS - 1) / GATHER_THREADS), dim3(GATHER_THREADS), 0,
+                       s, a);
   hipLaunchKernelGGL(k_search_by_projection_last, dim3(1), dim3(GUIDED_THREADS), 0, s, a);
 }
 
@@ -777,6 +820,9 @@ void launch_search_by_projection_points(const uint8_t* d_inView, const float* d_
   a.candCount = a.closedAt[1] + n;
   a.cand = (uint32_t*)(a.candCount + nPts);
   a.assigned = d_assigned; a.summary = d_summary;
+  a.gathered = gather_first(nPts);
+  if (a.gathered)
+    hipLaunchKernelGGL(k_gather_points, dim3((nPts + GATHER_THREADS - 1) / GATHER_THREADS), dim3(GATHER_THREADS), 0, s, a);
   hipLaunchKernelGGL(k_search_by_projection_points, dim3(1), dim3(GUIDED_THREADS), 0, s, a);
 }
 
@@ -817,6 +863,9 @@ void launch_search_for_initialization(const float* d_kps1Un, const uint8_t* d_de
   a.cand = (uint32_t*)(d_work + 6 * (size_t)n1);
   a.head = d_work + (6 + GUIDED_CACHE) * (size_t)n1;
   a.matches12 = d_matches12; a.summary = d_summary;
+  a.gathered = gather_first(n1);
+  if (a.gathered)
+    hipLaunchKernelGGL(k_gather_init, dim3((n1 + GATHER_THREADS - 1) / GATHER_THREADS), dim3(GATHER_THREADS), 0, s, a);
   hipLaunchKernelGGL(k_search_for_initialization, dim3(1), dim3(GUIDED_THREADS), 0, s, a);
 }
 

@@ -22,3 +22,12 @@ PY
 run two_pass_default A=1
 run single_pass ORBX_FAST_SINGLE_PASS=1
 for k in 2048 4096 8192; do run oct_keys_lds_$k ORBX_OCT_KEYS_LDS=$k; done
+# the guided matchers with and without a chip-wide launch for the window walks
+for g in 0 1; do
+  ORBX_GUIDED_GATHER=$g timeout -k 10 240 python bench.py --no-cpu --no-match --guided --steps 5 --warmup 2 > "$OUT/guided_gather_$g.log" 2>&1
+  python - "$OUT/guided_gather_$g.log" "$g" <<'PY'
+import json, sys
+j = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])["guided"]
+print("guided gather=%s: last frame %.3f ms, local map %.3f ms, by bow %.3f ms" % (sys.argv[2], j["value"], j["local_map"]["ms"], j["by_bow"]["ms"]))
+PY
+done
