@@ -46,7 +46,8 @@ def test_detector_controls(built, mode, racy):
     (["320", "200", "400", "synth"], {}),
     (["320", "200", "400", "noise"], {"ORBX_OCT_KEYS_LDS": "0"}),
     (["200", "160", "300", "faint"], {}),
-    (["320", "200", "400", "synth"], {"ORBX_FAST_SINGLE_PASS": "1", "HOSTSIM_ORDER": "reverse"}),
+    (["320", "200", "400", "synth"], {"ORBX_FAST_SINGLE_PASS": "1", "HOSTSIM_ORDER": "reverse",
+                                      "ORBX_GUIDED_GATHER": "0"}),
 ])
 def test_no_race_in_any_entry_point(built, args, env):
     code, out = run("race_driver", args, env)
