@@ -18,11 +18,15 @@ __global__ void k_neighbour(int* out, int mode) {
   out[t] = cell[src];
 }
 
-// device memory: every workgroup adds to the same word, plainly (mode 0) or atomically (mode 1)
+// device memory: every workgroup adds to the same word, plainly (mode 0) or atomically (mode 1).
+// Each does so many times: workgroups that follow each other on one worker thread of the
+// simulation count as ordered, so the control needs several workers busy at the same time.
 __global__ void k_counter(int* word, int mode) {
   if (threadIdx.x != 0) return;
-  if (mode == 0) *word = *word + 1;
-  else atomicAdd(word, 1);
+  for (int k = 0; k < 20000; ++k) {
+    if (mode == 0) *(volatile int*)word = *(volatile int*)word + 1;
+    else atomicAdd(word, 1);
+  }
 }
 
 int main(int argc, char** argv) {
