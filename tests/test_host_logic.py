@@ -84,3 +84,27 @@ def test_shard_bounds_cover_everything_once():
             assert b[0] == 0 and b[-1] == n and len(b) == world + 1
             assert all(b[i] <= b[i + 1] for i in range(world))
             assert all(x % 8 == 0 for x in b[:-1])
+
+
+def test_launch_block_sizes_match_launch_bounds():
+    """A launch with more threads than the kernel's __launch_bounds__ fails on the device and
+    nowhere else (the host simulation does not know the bounds): every hipLaunchKernelGGL in the
+    library names the same block size as the kernel's declaration."""
+    import glob
+    import re
+    src = "".join(open(f).read() for f in sorted(glob.glob(os.path.join(ROOT, "orb_slam3_amd", "csrc", "*.hip"))))
+    bounds = {m.group(2): m.group(1).strip()
+              for m in re.finditer(r"__global__\s+__launch_bounds__\(([^)]*)\)\s+void\s+(\w+)", src)}
+    assert not re.findall(r"__global__\s+void\s+\w+", src), "every kernel declares its launch bounds"
+    # launches whose block size is a variable: checked where it is computed
+    by_variable = {"k_pyr_level0": "256", "kern": None}
+    seen = 0
+    for m in re.finditer(r"hipLaunchKernelGGL\(\s*(?:orbx::)?(\w+)(?:<[^>]*>)?\s*,\s*(?:dim3\([^;]*?\)|[^,]+),"
+                         r"\s*(?:dim3\(([^)]*)\)|([^,]+)),", src, re.S):
+        kernel, block = m.group(1), (m.group(2) or m.group(3)).strip()
+        seen += 1
+        if kernel in by_variable:
+            continue
+        assert kernel in bounds, kernel
+        assert block == bounds[kernel], (kernel, block, bounds[kernel])
+    assert seen >= 30
