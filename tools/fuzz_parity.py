@@ -262,6 +262,22 @@ def grid_and_matchers(rng, img, params):
         n, rounds, n3m, rounds3, n2, rounds2, len(wi), nb)
 
 
+def batch_part(rng, img, params, lap):
+    """The frame inside a batch of three with other content before and after it: every frame of
+    the batch equals its single-frame extraction."""
+    h, w = img.shape
+    others = [content(rng, KINDS[int(rng.integers(0, len(KINDS)))], w, h) for _ in range(2)]
+    frames = [others[0], img, others[1]]
+    ex = orbx.ORBextractor(*params, max_batch=3)
+    res = ex.extract_batch(frames, lap)
+    single = orbx.ORBextractor(*params)
+    for f in range(3):
+        mono, k, d = single(frames[f], None, lap)
+        bm, bk, bd = res[f]
+        assert bm == mono and np.array_equal(bk, k), ("batch frame", f)
+        assert (d is None and bd is None) or np.array_equal(bd, d), ("batch descriptors", f)
+
+
 def knn_part(rng):
     """Brute-force 2-NN on random sizes; a small pool of distinct rows makes distance ties the rule."""
     nq, nt = int(rng.integers(1, 1300)), int(rng.choice([0, 1, 2, int(rng.integers(3, 6000))], p=[.03, .03, .04, .9]))
@@ -297,6 +313,8 @@ def main():
                 print("%s: %s" % (head, refused), flush=True)
                 continue
             bad = compare_full(oracle, img, params, lap)
+            if seed % 3 == 0:
+                batch_part(rng, img, params, lap)
             msg = "%d descriptor rows differ" % bad if bad else "extraction equal"
             nstereo = stereo_part(rng, img, params)
             rest = grid_and_matchers(rng, img, params)
