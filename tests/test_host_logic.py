@@ -108,3 +108,9 @@ def test_launch_block_sizes_match_launch_bounds():
         assert kernel in bounds, kernel
         assert block == bounds[kernel], (kernel, block, bounds[kernel])
     assert seen >= 30
+
+
+def test_header_is_plain_c():
+    """The boundary is a C ABI: include/orbx.h compiles as C99 with warnings as errors."""
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c",
+                           os.path.join(ROOT, "include", "orbx.h")])
