@@ -281,7 +281,10 @@ static inline int __float2int_rn(float v) { return (int)lrintf(v); }
 static inline int __float2int_rd(float v) { return (int)floorf(v); }
 static inline int __float2int_ru(float v) { return (int)ceilf(v); }
 static inline int __float2int_rz(float v) { return (int)v; }
-static inline int __mul24(int a, int b) { return (int)((uint32_t)((a << 8) >> 8) * (uint32_t)((b << 8) >> 8)); }
+static inline int __mul24(int a, int b) {
+  const int a24 = (int)((uint32_t)a << 8) >> 8, b24 = (int)((uint32_t)b << 8) >> 8;   // sign-extended low 24 bits
+  return (int)((uint32_t)a24 * (uint32_t)b24);
+}
 static inline uint32_t __umul24(uint32_t a, uint32_t b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
 static inline int __popc(uint32_t v) { return __builtin_popcount(v); }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }

@@ -286,7 +286,11 @@ static void prepare_fiber(Block* b, int i) {
 }
 
 static std::mutex g_blockMu;
-static std::vector<Block*> g_freeBlocks;
+// idle workgroup states; released when the process ends so that a leak check of the library's
+// host code reports only what the library leaks
+static struct BlockPool : std::vector<Block*> {
+  ~BlockPool();
+} g_freeBlocks;
 
 // per-worker state (fiber stacks, LDS region) is kept in a free list between launches
 static std::mutex g_allocMu;
@@ -314,6 +318,14 @@ static Block* acquire_block() {
   mprotect(blk->ldsRegion, kPage, PROT_NONE);
   mprotect(blk->ldsRegion + kPage + kLdsMax, kPage, PROT_NONE);
   return blk;
+}
+
+BlockPool::~BlockPool() {
+  for (Block* b : *this) {
+    if (b->stacks) munmap(b->stacks, (size_t)kMaxThreads * kStack);
+    if (b->ldsRegion) munmap(b->ldsRegion, kLdsMax + 2 * kPage);
+    delete b;
+  }
 }
 
 static void release_block(Block* b) {

@@ -54,3 +54,17 @@ def test_no_race_in_any_entry_point(built, args, env):
     assert "ThreadSanitizer" not in out, out[-6000:]
     assert code == 0, out[-3000:]
     assert "race_driver: done" in out
+
+
+def test_host_code_under_address_and_undefined_behaviour_sanitizers():
+    """The same driver with AddressSanitizer, LeakSanitizer and UBSan on every translation unit (the
+    library's host code included, and the kernels as compiled for the host): no report, nothing
+    leaked once the handles are destroyed."""
+    r = subprocess.run(["make", "-C", SIM, "-j8", "asan"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1")
+    out = subprocess.run([os.path.join(SIM, "_build", "asan", "race_driver"), "320", "200", "400", "synth"],
+                         capture_output=True, text=True, env=env, timeout=900)
+    text = out.stdout + out.stderr
+    assert out.returncode == 0 and "ERROR" not in text and "runtime error" not in text, text[-4000:]
+    assert "race_driver: done" in text
