@@ -34,9 +34,11 @@ HOSTSIM = os.environ.get("ORBX_HOSTSIM") == "1"
 def _load_hostsim():
     import ctypes
     sim_dir = os.path.join(ROOT, "tests", "hostsim")
-    subprocess.check_call(["make", "-C", sim_dir, "-j8"], stdout=subprocess.DEVNULL)
+    # ORBX_HOSTSIM_LIB=ubsan: the build with undefined-behaviour checks compiled in as traps
+    variant = os.environ.get("ORBX_HOSTSIM_LIB", "")
+    subprocess.check_call(["make", "-C", sim_dir, "-j8", variant or "all"], stdout=subprocess.DEVNULL)
     from orb_slam3_amd import _lib
-    handle = ctypes.CDLL(os.path.join(sim_dir, "_build", "liborbx_hostsim.so"), mode=ctypes.RTLD_LOCAL)
+    handle = ctypes.CDLL(os.path.join(sim_dir, "_build", variant, "liborbx_hostsim.so"), mode=ctypes.RTLD_LOCAL)
     for name, (res, args) in _lib.SIGNATURES.items():
         fn = getattr(handle, name)
         fn.restype = res

@@ -23,10 +23,12 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("guard,order", [("end", "forward"), ("start", "forward"), ("end", "reverse"),
-                                         ("end", "shuffle:7")])
-def test_gpu_suite_under_host_simulation(guard, order):
-    env = dict(os.environ, ORBX_HOSTSIM="1", HOSTSIM_GUARD=guard, HOSTSIM_ORDER=order)
+@pytest.mark.parametrize("guard,order,lib", [("end", "forward", ""), ("start", "forward", "ubsan"),
+                                             ("end", "reverse", ""), ("end", "shuffle:7", "")])
+def test_gpu_suite_under_host_simulation(guard, order, lib):
+    # lib "ubsan": the simulation built with every undefined-behaviour check (signed overflow,
+    # shifts, misaligned or null accesses ...) compiled in as a trap
+    env = dict(os.environ, ORBX_HOSTSIM="1", HOSTSIM_GUARD=guard, HOSTSIM_ORDER=order, ORBX_HOSTSIM_LIB=lib)
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests"), "-m", "gpu", "-q", "-x",
                           "-p", "no:faulthandler", "-p", "no:cacheprovider"],
                          cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
