@@ -5,10 +5,11 @@ by thread: device allocations and dynamic LDS sit against guard pages, so an out
 access of any kernel stops the run; lanes of a wave that meet at different cross-lane
 operations are reported; and because the simulated kernels execute the same source, their
 outputs can be compared with the CPU oracle.  Here the whole GPU-marked suite is run against
-that build, once with the guard page behind every allocation, once in front of it, once with
-the threads of every workgroup scheduled from the last to the first, and once with waves and lanes
-in a fresh pseudo-random order at every sweep of the scheduler (a result that depends on which
-thread reaches a point first - a missing barrier, an order-dependent use of atomics - would change).
+that build three times: with the guard page behind every allocation; with the guard page in front,
+the threads of every workgroup scheduled from the last to the first and every undefined-behaviour
+check compiled in as a trap; and with waves and lanes in a fresh pseudo-random order at every
+sweep of the scheduler (a result that depends on which thread reaches a point first - a missing
+barrier, an order-dependent use of atomics - would change).
 
 This is a check of the kernels' addressing and logic.  It is not a GPU parity result (the
 GPU tests proper are the ones marked `gpu`, run on the MI355X) and nothing in the package
@@ -23,8 +24,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("guard,order,lib", [("end", "forward", ""), ("start", "forward", "ubsan"),
-                                             ("end", "reverse", ""), ("end", "shuffle:7", "")])
+@pytest.mark.parametrize("guard,order,lib", [("end", "forward", ""), ("start", "reverse", "ubsan"),
+                                             ("end", "shuffle:7", "")])
 def test_gpu_suite_under_host_simulation(guard, order, lib):
     # lib "ubsan": the simulation built with every undefined-behaviour check (signed overflow,
     # shifts, misaligned or null accesses ...) compiled in as a trap
