@@ -757,15 +757,16 @@ static GridView make_grid(const float* d_kpsUn, const int* d_cellStart, const in
 }
 
 // Whether the window walks get a launch of their own (ORBX_GUIDED_GATHER=0 / 1 forces it off /
-// on; results are the same either way): worth a second launch once the queries outnumber what a
-// few waves of one CU would walk anyway.
+// on; results are the same either way).  With at most one query per thread of the rounds kernel
+// the walks already run side by side there, each a chain of dependent loads, and a second launch
+// would only add its own latency; it pays once threads would have to walk several queries in turn.
 static int gather_first(int nQueries) {
   static const int forced = [] {
     const char* e = getenv("ORBX_GUIDED_GATHER");
     return e ? (atoi(e) != 0 ? 1 : 0) : -1;
   }();
   if (forced >= 0) return forced;
-  return nQueries >= 256 ? 1 : 0;
+  return nQueries > GUIDED_THREADS ? 1 : 0;
 }
 
 // work memory either launcher needs beyond its inputs and outputs, in ints

@@ -44,7 +44,7 @@ def test_detector_controls(built, mode, racy):
 
 @pytest.mark.parametrize("args,env", [
     (["320", "200", "400", "synth"], {}),
-    (["320", "200", "400", "noise"], {"ORBX_OCT_KEYS_LDS": "0"}),
+    (["320", "200", "400", "noise"], {"ORBX_OCT_KEYS_LDS": "0", "ORBX_GUIDED_GATHER": "1"}),
     (["200", "160", "300", "faint"], {}),
     (["320", "200", "400", "synth"], {"ORBX_FAST_SINGLE_PASS": "1", "HOSTSIM_ORDER": "reverse",
                                       "ORBX_GUIDED_GATHER": "0"}),
