@@ -32,7 +32,10 @@ typedef enum orbx_status {
   ORBX_ERR_NO_DEVICE = -5,    /* no usable HIP device / HIP runtime error at set-up */
   ORBX_ERR_HIP = -6,          /* HIP runtime error during a call */
   ORBX_ERR_UNSUPPORTED = -7,  /* parameters beyond what the kernels are sized for */
-  ORBX_ERR_BATCH = -8         /* more frames than the handle's max_batch */
+  ORBX_ERR_BATCH = -8,        /* more frames than the handle's max_batch */
+  ORBX_ERR_SCRATCH = -9,      /* input beyond what the fixed scratch buffer of an allocation-free
+                               * entry point holds */
+  ORBX_ERR_COMM = -10         /* RCCL library missing or an RCCL call failed */
 } orbx_status;
 
 /* cv::KeyPoint layout (28 bytes): pt.x, pt.y, size, angle, response, octave, class_id. */
@@ -174,9 +177,37 @@ int orbx_knn2(int device_id, const uint8_t* q, int nq, const uint8_t* t, int64_t
 int orbx_knn2_device(const uint8_t* d_q, int nq, const uint8_t* d_t, int64_t nt,
                      uint32_t index_offset, uint32_t* d_idx, uint16_t* d_dist, void* stream);
 /* Merge nparts partial 2-NN results (layout [part][nq][2]) into the global
- * 2-NN with the same (distance, index) ordering.  Device pointers. */
+ * 2-NN with the same (distance, index) ordering.  Device pointers; the index
+ * array 8-byte and the distance array 4-byte aligned. */
 int orbx_top2_merge_device(const uint32_t* d_idx_parts, const uint16_t* d_dist_parts, int nparts,
                            int nq, uint32_t* d_idx, uint16_t* d_dist, void* stream);
+
+/* ---- 2-NN against a train set sharded over the GPUs of a node ---------------- */
+/* One process per GPU.  The query rows are replicated, every rank holds one
+ * contiguous range of the train rows (a keyframe descriptor database, the
+ * scaled-up form of core/src/Frame.cc:1177); the only exchange is one
+ * all-gather of the per-rank top-2 records over RCCL, followed by the merge of
+ * orbx_top2_merge_device in rank order.  With contiguous ranges in rank order
+ * that is global index order, so results equal the unsharded orbx_knn2_device
+ * bit for bit, ties included.
+ *
+ * nccl_comm: an ncclComm_t (as void*) whose ranks each call this function with
+ * the same nq and their own shard; shard_offset = global index of the shard's
+ * first row.  d_workspace: orbx_knn2_sharded_workspace_bytes(nranks, nq) bytes
+ * of device memory, 256-byte aligned, or NULL (then the call allocates
+ * stream-ordered memory itself).  Asynchronous on stream; every rank receives
+ * the global result.  RCCL is taken from the copy already loaded in the process,
+ * else from librccl.so.1 on the loader path; ORBX_ERR_COMM if neither exists. */
+int orbx_knn2_sharded(void* nccl_comm, const uint8_t* d_q, int nq, const uint8_t* d_t_shard,
+                      int64_t nt_shard, uint32_t shard_offset, uint32_t* d_idx, uint16_t* d_dist,
+                      void* d_workspace, size_t workspace_bytes, void* stream);
+size_t orbx_knn2_sharded_workspace_bytes(int nranks, int nq);
+/* For callers without an RCCL binding of their own: ncclGetUniqueId (128 bytes,
+ * made by one rank and handed to the others by any means), ncclCommInitRank on
+ * device_id, ncclCommDestroy. */
+int orbx_rccl_unique_id(uint8_t* id128);
+int orbx_rccl_comm_create(const uint8_t* id128, int nranks, int rank, int device_id, void** comm);
+int orbx_rccl_comm_destroy(void* comm);
 
 /* Row-band stereo descriptor search: the first half of
  * Frame::ComputeStereoMatches, core/src/Frame.cc:840-908.  For each left

@@ -24,6 +24,8 @@ ORBX_ERR_NO_DEVICE = -5
 ORBX_ERR_HIP = -6
 ORBX_ERR_UNSUPPORTED = -7
 ORBX_ERR_BATCH = -8
+ORBX_ERR_SCRATCH = -9
+ORBX_ERR_COMM = -10
 NUM_STAGES = 6
 STAGE_NAMES = ("pyramid", "fast", "octree", "assemble", "blur", "describe")
 
@@ -81,6 +83,11 @@ SIGNATURES = {
     "orbx_hamming": (C.c_int, [_P, _P]),
     "orbx_knn2": (C.c_int, [C.c_int, _P, C.c_int, _P, C.c_int64, _P, _P]),
     "orbx_knn2_device": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_uint32, _P, _P, _P]),
+    "orbx_knn2_sharded": (C.c_int, [_P, _P, C.c_int, _P, C.c_int64, C.c_uint32, _P, _P, _P, C.c_size_t, _P]),
+    "orbx_knn2_sharded_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "orbx_rccl_unique_id": (C.c_int, [_P]),
+    "orbx_rccl_comm_create": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    "orbx_rccl_comm_destroy": (C.c_int, [_P]),
     "orbx_top2_merge_device": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),
     "orbx_stereo_band_match": (C.c_int, [C.c_int, _P, _P, C.c_int, _P, _P, C.c_int, _f32p, C.c_int,
                                          C.c_int, C.c_float, C.c_float, _P, _P]),

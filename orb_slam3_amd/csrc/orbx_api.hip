@@ -630,6 +630,8 @@ const char* orbx_strerror(int status) {
     case ORBX_ERR_HIP: return "HIP runtime error";
     case ORBX_ERR_UNSUPPORTED: return "parameters beyond what the kernels are sized for";
     case ORBX_ERR_BATCH: return "more frames than the handle's max_batch";
+    case ORBX_ERR_SCRATCH: return "input too large for the fixed scratch buffer of the allocation-free entry point";
+    case ORBX_ERR_COMM: return "RCCL library not found or an RCCL call failed";
     default: return "unknown status";
   }
 }

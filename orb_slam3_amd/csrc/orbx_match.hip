@@ -14,6 +14,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "../../include/orbx.h"
@@ -23,6 +24,7 @@ namespace orbx {
 #define KNN_QPL 2          // queries per lane
 #define KNN_BLOCK 256
 #define KNN_IDX_BITS 22    // train rows per scan segment <= 2^22
+#define KNN_ROWS 4          // train rows per step of the scan
 
 // Candidates are ranked by the 32-bit word (distance << 22 | local train
 // index): its unsigned order is exactly (distance, index) ascending, the
@@ -50,17 +52,57 @@ __global__ __launch_bounds__(KNN_BLOCK) void k_knn2(const uint32_t* __restrict__
     k1[u] = 0xFFFFFFFFu;
   }
   const uint32_t* tp = t + (size_t)t0 * 8;
-#pragma unroll 4
-  for (int j = 0; j < len; ++j) {
+  // Steps of KNN_ROWS train rows.  A row can only enter a query's pair when its distance is
+  // below the distance of the current second neighbour (rows arrive in ascending index, so an
+  // equal distance loses the tie): one compare per pair decides, and the key arithmetic runs
+  // only in the steps where some lane of the wave has such a row - after the first few hundred
+  // rows of a segment that is a small fraction of the steps.
+  uint32_t th[KNN_QPL];
+#pragma unroll
+  for (int u = 0; u < KNN_QPL; ++u) th[u] = 0xFFFFFFFFu >> KNN_IDX_BITS;
+  int j = 0;
+  for (; j + KNN_ROWS <= len; j += KNN_ROWS) {
+    uint32_t tv[KNN_ROWS][8];
+#pragma unroll
+    for (int r = 0; r < KNN_ROWS; ++r)
+#pragma unroll
+      for (int w = 0; w < 8; ++w) tv[r][w] = tp[(size_t)(j + r) * 8 + w];  // wave-uniform -> scalar loads
+    uint32_t d[KNN_QPL][KNN_ROWS];
+    bool any = false;
+#pragma unroll
+    for (int u = 0; u < KNN_QPL; ++u)
+#pragma unroll
+      for (int r = 0; r < KNN_ROWS; ++r) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) c += __builtin_popcount(qa[u][w] ^ tv[r][w]);
+        d[u][r] = c;
+        any |= c < th[u];
+      }
+    if (__any(any)) {
+#pragma unroll
+      for (int u = 0; u < KNN_QPL; ++u) {
+#pragma unroll
+        for (int r = 0; r < KNN_ROWS; ++r) {
+          const uint32_t key = (d[u][r] << KNN_IDX_BITS) | (uint32_t)(j + r);
+          const uint32_t hi = max(k0[u], key);
+          k0[u] = min(k0[u], key);
+          k1[u] = min(k1[u], hi);
+        }
+        th[u] = k1[u] >> KNN_IDX_BITS;
+      }
+    }
+  }
+  for (; j < len; ++j) {
     uint32_t tv[8];
 #pragma unroll
-    for (int w = 0; w < 8; ++w) tv[w] = tp[(size_t)j * 8 + w];  // wave-uniform -> scalar loads
+    for (int w = 0; w < 8; ++w) tv[w] = tp[(size_t)j * 8 + w];
 #pragma unroll
     for (int u = 0; u < KNN_QPL; ++u) {
-      uint32_t d = 0;
+      uint32_t c = 0;
 #pragma unroll
-      for (int w = 0; w < 8; ++w) d += __builtin_popcount(qa[u][w] ^ tv[w]);
-      const uint32_t key = (d << KNN_IDX_BITS) | (uint32_t)j;
+      for (int w = 0; w < 8; ++w) c += __builtin_popcount(qa[u][w] ^ tv[w]);
+      const uint32_t key = (c << KNN_IDX_BITS) | (uint32_t)j;
       const uint32_t hi = max(k0[u], key);
       k0[u] = min(k0[u], key);
       k1[u] = min(k1[u], hi);
@@ -81,23 +123,26 @@ __global__ __launch_bounds__(KNN_BLOCK) void k_knn2(const uint32_t* __restrict__
   }
 }
 
-// Merge partial 2-NN lists [part][nq][2] by (distance, index); parts are
-// visited in order and comparisons are strict, so equal (distance, index)
-// pairs cannot reorder and the earliest index wins a distance tie.
-__global__ __launch_bounds__(256) void k_top2_merge(const uint32_t* __restrict__ idx_parts,
-                                                    const uint16_t* __restrict__ dist_parts,
+// Merge partial 2-NN lists by (distance, index); part p holds its nq*2 indices at idx_parts +
+// p*idx_stride bytes and its nq*2 distances at dist_parts + p*dist_stride bytes.  Parts are
+// visited in order and comparisons are strict, so equal (distance, index) pairs cannot reorder
+// and the earliest index wins a distance tie.
+__global__ __launch_bounds__(256) void k_top2_merge(const uint8_t* __restrict__ idx_parts, size_t idx_stride,
+                                                    const uint8_t* __restrict__ dist_parts, size_t dist_stride,
                                                     int nparts, int nq, uint32_t* __restrict__ idx,
                                                     uint16_t* __restrict__ dist) {
   const int qi = blockIdx.x * 256 + threadIdx.x;
   if (qi >= nq) return;
   unsigned long long b0 = ~0ull, b1 = ~0ull;
   for (int p = 0; p < nparts; ++p) {
-    const size_t o = ((size_t)p * nq + qi) * 2;
+    const uint2 pi = ((const uint2*)(idx_parts + (size_t)p * idx_stride))[qi];
+    const uint32_t pd = ((const uint32_t*)(dist_parts + (size_t)p * dist_stride))[qi];
+    const unsigned long long key[2] = {((unsigned long long)(pd & 0xFFFFu) << 32) | pi.x,
+                                       ((unsigned long long)(pd >> 16) << 32) | pi.y};
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      const unsigned long long key = ((unsigned long long)dist_parts[o + e] << 32) | idx_parts[o + e];
-      const unsigned long long hi = key > b0 ? key : b0;
-      b0 = key < b0 ? key : b0;
+      const unsigned long long hi = key[e] > b0 ? key[e] : b0;
+      b0 = key[e] < b0 ? key[e] : b0;
       b1 = hi < b1 ? hi : b1;
     }
   }
@@ -150,6 +195,15 @@ __global__ __launch_bounds__(256) void k_stereo_band(const KP* __restrict__ kl,
 
 }  // namespace orbx
 
+namespace orbx {
+void launch_top2_merge_strided(const uint8_t* idx_parts, size_t idx_stride, const uint8_t* dist_parts,
+                               size_t dist_stride, int nparts, int nq, uint32_t* idx, uint16_t* dist,
+                               hipStream_t s) {
+  hipLaunchKernelGGL(k_top2_merge, dim3((nq + 255) / 256), dim3(256), 0, s, idx_parts, idx_stride, dist_parts,
+                     dist_stride, nparts, nq, idx, dist);
+}
+}  // namespace orbx
+
 namespace {
 struct DevBuf {
   void* p = nullptr;
@@ -171,50 +225,81 @@ int orbx_hamming(const uint8_t* a, const uint8_t* b) {
   return d;
 }
 
-// Partial results for nsegs train segments need nsegs*nq*2 entries of scratch.
-static int knn2_launch(const uint8_t* d_q, int nq, const uint8_t* d_t, int64_t nt,
-                       uint32_t index_offset, uint32_t* d_idx, uint16_t* d_dist, hipStream_t s) {
-  if (nq <= 0) return ORBX_OK;
-  const int qblocks = (nq + KNN_QPL * KNN_BLOCK - 1) / (KNN_QPL * KNN_BLOCK);
-  // enough segments to occupy the chip when there are few query blocks
-  long long segs = 1;
+// How a scan of nt train rows for nq queries is cut into segments (grid y): enough segments to
+// occupy the chip when there are few query blocks, none longer than the key's index field, and
+// - when the partial results must fit a fixed buffer - no more than that buffer holds.
+struct KnnCut { int qblocks; long long segs; int seg_len; };
+static const size_t kPartialBytesPerQuery = 12;   // two uint32 indices + two uint16 distances
+
+static int knn2_cut(int nq, int64_t nt, size_t partial_budget, KnnCut* c) {
+  c->qblocks = (nq + KNN_QPL * KNN_BLOCK - 1) / (KNN_QPL * KNN_BLOCK);
+  long long segs = 1, minSegs = 1;
   if (nt > 0) {
-    const long long want = (2048 + qblocks - 1) / qblocks;
+    const long long want = (2048 + c->qblocks - 1) / c->qblocks;
     const long long minLen = 512;
     segs = std::max(1LL, std::min(want, (long long)((nt + minLen - 1) / minLen)));
     const long long maxLen = 1LL << KNN_IDX_BITS;
-    segs = std::max(segs, (long long)((nt + maxLen - 1) / maxLen));
+    minSegs = (long long)((nt + maxLen - 1) / maxLen);
+    segs = std::max(segs, minSegs);
   }
-  const int seg_len = nt > 0 ? (int)((nt + segs - 1) / segs) : 1;
-  segs = nt > 0 ? (nt + seg_len - 1) / seg_len : 1;
-  if (segs > 65535) return ORBX_ERR_UNSUPPORTED;
-  if (segs == 1) {
-    hipLaunchKernelGGL(orbx::k_knn2, dim3(qblocks, 1), dim3(KNN_BLOCK), 0, s, (const uint32_t*)d_q, nq,
-                       (const uint32_t*)d_t, (long long)nt, seg_len, index_offset, d_idx, d_dist);
+  if (partial_budget != (size_t)-1 && segs > 1) {
+    const long long fit = (long long)(partial_budget / ((size_t)nq * kPartialBytesPerQuery + 512));
+    if (fit < minSegs || (fit < 2 && minSegs > 1)) return ORBX_ERR_SCRATCH;
+    segs = std::max(minSegs, std::min(segs, std::max(fit, 1LL)));
+  }
+  c->seg_len = nt > 0 ? (int)((nt + segs - 1) / segs) : 1;
+  c->segs = nt > 0 ? (nt + c->seg_len - 1) / c->seg_len : 1;
+  if (c->segs > 65535) return ORBX_ERR_UNSUPPORTED;
+  return ORBX_OK;
+}
+
+static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+
+// The scan and, for more than one segment, the merge of the segments' partial results, which
+// live in `partial` (align256(segs*nq*8) bytes of indices, then segs*nq*4 bytes of distances).
+static int knn2_enqueue(const KnnCut& c, const uint8_t* d_q, int nq, const uint8_t* d_t, int64_t nt,
+                        uint32_t index_offset, uint32_t* d_idx, uint16_t* d_dist, uint8_t* partial,
+                        hipStream_t s) {
+  if (c.segs == 1) {
+    hipLaunchKernelGGL(orbx::k_knn2, dim3(c.qblocks, 1), dim3(KNN_BLOCK), 0, s, (const uint32_t*)d_q, nq,
+                       (const uint32_t*)d_t, (long long)nt, c.seg_len, index_offset, d_idx, d_dist);
   } else {
-    uint32_t* pidx = nullptr;
-    uint16_t* pdist = nullptr;
-    if (hipMallocAsync((void**)&pidx, (size_t)segs * nq * 2 * 4, s) != hipSuccess) return ORBX_ERR_HIP;
-    if (hipMallocAsync((void**)&pdist, (size_t)segs * nq * 2 * 2, s) != hipSuccess) {
-      (void)hipFreeAsync(pidx, s);
-      return ORBX_ERR_HIP;
-    }
-    hipLaunchKernelGGL(orbx::k_knn2, dim3(qblocks, (unsigned)segs), dim3(KNN_BLOCK), 0, s,
-                       (const uint32_t*)d_q, nq, (const uint32_t*)d_t, (long long)nt, seg_len,
-                       index_offset, pidx, pdist);
-    hipLaunchKernelGGL(orbx::k_top2_merge, dim3((nq + 255) / 256), dim3(256), 0, s, pidx, pdist,
-                       (int)segs, nq, d_idx, d_dist);
-    (void)hipFreeAsync(pidx, s);
-    (void)hipFreeAsync(pdist, s);
+    uint8_t* pidx = partial;
+    uint8_t* pdist = partial + align256((size_t)c.segs * nq * 8);
+    hipLaunchKernelGGL(orbx::k_knn2, dim3(c.qblocks, (unsigned)c.segs), dim3(KNN_BLOCK), 0, s,
+                       (const uint32_t*)d_q, nq, (const uint32_t*)d_t, (long long)nt, c.seg_len,
+                       index_offset, (uint32_t*)pidx, (uint16_t*)pdist);
+    hipLaunchKernelGGL(orbx::k_top2_merge, dim3((nq + 255) / 256), dim3(256), 0, s, pidx, (size_t)nq * 8,
+                       pdist, (size_t)nq * 4, (int)c.segs, nq, d_idx, d_dist);
   }
   return hipGetLastError() == hipSuccess ? ORBX_OK : ORBX_ERR_HIP;
 }
 
+static int knn2_launch(const uint8_t* d_q, int nq, const uint8_t* d_t, int64_t nt,
+                       uint32_t index_offset, uint32_t* d_idx, uint16_t* d_dist, hipStream_t s) {
+  if (nq <= 0) return ORBX_OK;
+  KnnCut c;
+  int st = knn2_cut(nq, nt, (size_t)-1, &c);
+  if (st != ORBX_OK) return st;
+  uint8_t* partial = nullptr;
+  if (c.segs > 1 &&
+      hipMallocAsync((void**)&partial, align256((size_t)c.segs * nq * 8) + (size_t)c.segs * nq * 4, s) != hipSuccess)
+    return ORBX_ERR_HIP;
+  st = knn2_enqueue(c, d_q, nq, d_t, nt, index_offset, d_idx, d_dist, partial, s);
+  if (partial) (void)hipFreeAsync(partial, s);
+  return st;
+}
+
+static bool knn2_args_ok(const uint8_t* d_q, int nq, const uint8_t* d_t, int64_t nt, const uint32_t* d_idx,
+                         const uint16_t* d_dist) {
+  if (nq < 0 || nt < 0 || (nq > 0 && (!d_q || !d_idx || !d_dist)) || (nt > 0 && !d_t)) return false;
+  if (((uintptr_t)d_q | (uintptr_t)d_t) & 15) return false;   // rows are read as 16-byte words
+  return true;
+}
+
 int orbx_knn2_device(const uint8_t* d_q, int nq, const uint8_t* d_t, int64_t nt, uint32_t index_offset,
                      uint32_t* d_idx, uint16_t* d_dist, void* stream) {
-  if (nq < 0 || nt < 0 || (nq > 0 && (!d_q || !d_idx || !d_dist)) || (nt > 0 && !d_t))
-    return ORBX_ERR_BAD_ARG;
-  if (((uintptr_t)d_q | (uintptr_t)d_t) & 15) return ORBX_ERR_BAD_ARG;  // rows are read as 16-byte words
+  if (!knn2_args_ok(d_q, nq, d_t, nt, d_idx, d_dist)) return ORBX_ERR_BAD_ARG;
   return knn2_launch(d_q, nq, d_t, nt, index_offset, d_idx, d_dist, (hipStream_t)stream);
 }
 
@@ -222,9 +307,11 @@ int orbx_top2_merge_device(const uint32_t* d_idx_parts, const uint16_t* d_dist_p
                            uint32_t* d_idx, uint16_t* d_dist, void* stream) {
   if (nparts < 1 || nq < 0 || (nq > 0 && (!d_idx_parts || !d_dist_parts || !d_idx || !d_dist)))
     return ORBX_ERR_BAD_ARG;
+  if (((uintptr_t)d_idx_parts & 7) || ((uintptr_t)d_dist_parts & 3)) return ORBX_ERR_BAD_ARG;
   if (nq == 0) return ORBX_OK;
   hipLaunchKernelGGL(orbx::k_top2_merge, dim3((nq + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                     d_idx_parts, d_dist_parts, nparts, nq, d_idx, d_dist);
+                     (const uint8_t*)d_idx_parts, (size_t)nq * 8, (const uint8_t*)d_dist_parts, (size_t)nq * 4,
+                     nparts, nq, d_idx, d_dist);
   return hipGetLastError() == hipSuccess ? ORBX_OK : ORBX_ERR_HIP;
 }
 

@@ -120,19 +120,72 @@ def shard_bounds(n_rows, world):
     return b
 
 
-def knn_match2_sharded(query_t, train_shard_t, shard_offset, group=None, _hooks=None):
+class RcclComm:
+    """An RCCL communicator of this process's own for the sharded matcher, one rank per GPU.
+    The 128-byte unique id is made by rank 0 through the library and handed to the other ranks
+    over the torch.distributed group (any backend: the hand-over is host data)."""
+
+    def __init__(self, device_index, group=None):
+        import torch
+        import torch.distributed as dist
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        uid = np.zeros(128, np.uint8)
+        if self.rank == 0:
+            check(lib().orbx_rccl_unique_id(ptr(uid)), "orbx_rccl_unique_id")
+        if self.world > 1:
+            box = [uid.tobytes()]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0,
+                                       group=group)
+            uid = np.frombuffer(box[0], np.uint8).copy()
+        h = C.c_void_p()
+        check(lib().orbx_rccl_comm_create(ptr(uid), self.world, self.rank, int(device_index), C.byref(h)),
+              "orbx_rccl_comm_create")
+        self._h = h
+        self._ws = None   # workspace tensor, grown on demand
+
+    def workspace(self, nq, device):
+        import torch
+        need = int(lib().orbx_knn2_sharded_workspace_bytes(self.world, int(nq)))
+        if self._ws is None or self._ws.numel() < need or self._ws.device != device:
+            self._ws = torch.empty(max(need, 256), dtype=torch.uint8, device=device)
+        return self._ws, need
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().orbx_rccl_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+_comms = {}
+
+
+def _comm_for(group, device):
+    key = (id(group) if group is not None else None, device.index)
+    if key not in _comms:
+        _comms[key] = RcclComm(device.index, group)
+    return _comms[key]
+
+
+def knn_match2_sharded(query_t, train_shard_t, shard_offset, group=None, comm=None, _hooks=None):
     """Brute-force 2-NN against a train set sharded over the ranks of a
     torch.distributed group (one process per GPU, RCCL over xGMI).
 
     query_t: (nq, 32) uint8 CUDA tensor replicated on every rank; train_shard_t: this
     rank's contiguous slice of the train rows, whose first row has global index
     shard_offset.  Every rank returns the global (idx int32[nq,2], dist int16[nq,2])
-    tensors (bit patterns of uint32 / uint16).  The only exchange is one all-gather of
-    the per-shard top-2 records; the merge is a HIP kernel.
+    tensors (bit patterns of uint32 / uint16).  CUDA tensors go through the C entry point
+    orbx_knn2_sharded (per-shard search, one RCCL all-gather of the per-shard top-2 records,
+    merge kernel) on an RcclComm that is created on first use per (group, device) or passed
+    in as `comm`.
 
-    _hooks = (local_search, merge) replaces the two HIP calls; it exists so the
-    world_size-2 gloo test can drive this exchange on CPU tensors.  Without hooks CPU
-    tensors are rejected: there is no CPU implementation in this package."""
+    _hooks = (local_search, merge) replaces the two HIP calls and moves the records with the
+    group's own all-gather; it exists so the world_size-2 gloo test can drive the sharding,
+    offsets and merge order on CPU tensors.  Without hooks CPU tensors are rejected: there is
+    no CPU implementation in this package."""
     import torch
     import torch.distributed as dist
 
@@ -142,33 +195,22 @@ def knn_match2_sharded(query_t, train_shard_t, shard_offset, group=None, _hooks=
         if not query_t.is_cuda or not train_shard_t.is_cuda:
             raise RuntimeError("knn_match2_sharded needs CUDA tensors (no CPU fallback)")
         dev = query_t.device
+        q, t = query_t.contiguous(), train_shard_t.contiguous()
+        c = comm if comm is not None else _comm_for(group, dev)
+        ws, need = c.workspace(nq, dev)
+        idx = torch.empty((nq, 2), dtype=torch.int32, device=dev)
+        dst = torch.empty((nq, 2), dtype=torch.int16, device=dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
-
-        def local_search(q, t, off):
-            idx = torch.empty((nq, 2), dtype=torch.int32, device=dev)
-            dst = torch.empty((nq, 2), dtype=torch.int16, device=dev)
-            check(lib().orbx_knn2_device(C.c_void_p(q.data_ptr()), nq, C.c_void_p(t.data_ptr()),
-                                         t.shape[0], int(off), C.c_void_p(idx.data_ptr()),
-                                         C.c_void_p(dst.data_ptr()), C.c_void_p(stream)),
-                  "orbx_knn2_device")
-            return idx, dst
-
-        def merge(idx_all, dst_all):
-            out_i = torch.empty((nq, 2), dtype=torch.int32, device=dev)
-            out_d = torch.empty((nq, 2), dtype=torch.int16, device=dev)
-            check(lib().orbx_top2_merge_device(C.c_void_p(idx_all.data_ptr()),
-                                               C.c_void_p(dst_all.data_ptr()), idx_all.shape[0], nq,
-                                               C.c_void_p(out_i.data_ptr()), C.c_void_p(out_d.data_ptr()),
-                                               C.c_void_p(stream)), "orbx_top2_merge_device")
-            return out_i, out_d
-    else:
-        local_search, merge = _hooks
-
+        check(lib().orbx_knn2_sharded(c._h, C.c_void_p(q.data_ptr()), nq, C.c_void_p(t.data_ptr()), t.shape[0],
+                                      int(shard_offset), C.c_void_p(idx.data_ptr()), C.c_void_p(dst.data_ptr()),
+                                      C.c_void_p(ws.data_ptr()), need, C.c_void_p(stream)), "orbx_knn2_sharded")
+        return idx, dst
+    local_search, merge = _hooks
     idx, dst = local_search(query_t.contiguous(), train_shard_t.contiguous(), shard_offset)
     if world == 1:
         return idx, dst
     idx_all = torch.empty((world * nq, 2), dtype=idx.dtype, device=idx.device)
-    # 16-bit integers are not a collective dtype (neither RCCL nor gloo): ship the bytes
+    # 16-bit integers are not a collective dtype of gloo: ship the bytes
     dst_all = torch.empty((world * nq, 4), dtype=torch.uint8, device=dst.device)
     dist.all_gather_into_tensor(idx_all, idx.contiguous(), group=group)
     dist.all_gather_into_tensor(dst_all, dst.contiguous().view(torch.uint8), group=group)

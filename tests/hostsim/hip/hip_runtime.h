@@ -68,6 +68,13 @@ typedef hostsim_event* hipEvent_t;
 enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0 };
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 
+// a file-scope __device__ array is an ordinary host array here: its "device address" is its own
+#define HIP_SYMBOL(x) x
+template <class T> inline hipError_t hipGetSymbolAddress(void** p, const T& symbol) {
+  *p = (void*)&symbol;
+  return hipSuccess;
+}
+
 extern "C" {
 hipError_t hipMalloc(void** p, size_t n);
 hipError_t hipFree(void* p);

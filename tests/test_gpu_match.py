@@ -190,3 +190,143 @@ def test_knn2_large_properties():
         d = lut[np.bitwise_xor(t_np, q_np[qi])].sum(axis=1)
         order = np.lexsort((np.arange(nt), d))[:2]
         assert i_np[qi].tolist() == order.tolist() and d_np[qi].tolist() == d[order].tolist()
+
+
+@pytest.mark.needs_real_device
+def test_knn2_sharded_entry_point_single_rank(oracle):
+    """orbx_knn2_sharded through a one-rank RCCL communicator of the library's own making: the
+    per-shard search, the all-gather call and the merge run as they do on N ranks, and the result
+    equals the unsharded search (workspace given by the caller, then allocated by the call)."""
+    import ctypes as C
+    import torch
+    from orb_slam3_amd._lib import lib, check
+    from orb_slam3_amd.matcher import RcclComm
+    rng = np.random.default_rng(21)
+    q, t = planted(rng, 900, 30000)
+    ridx, rdist = oracle.knn2(q, t)
+    dq, dt = torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda()
+    comm = RcclComm(0)
+    assert comm.world == 1
+    i, d = orbx.knn_match2_sharded(dq, dt, 0, comm=comm)
+    torch.cuda.synchronize()
+    assert np.array_equal(i.cpu().numpy().view(np.uint32), ridx)
+    assert np.array_equal(d.cpu().numpy().view(np.uint16), rdist)
+    # a shard that starts at a global offset, workspace left to the call
+    oi = torch.empty((len(q), 2), dtype=torch.int32, device="cuda")
+    od = torch.empty((len(q), 2), dtype=torch.int16, device="cuda")
+    check(lib().orbx_knn2_sharded(comm._h, C.c_void_p(dq.data_ptr()), len(q), C.c_void_p(dt.data_ptr()), len(t),
+                                  5000, C.c_void_p(oi.data_ptr()), C.c_void_p(od.data_ptr()), None, 0, None))
+    torch.cuda.synchronize()
+    assert np.array_equal(oi.cpu().numpy().view(np.uint32), ridx + np.uint32(5000))
+    assert np.array_equal(od.cpu().numpy().view(np.uint16), rdist)
+    comm.close()
+
+
+def _two_gpu_worker(rank, world, port, q, t, out):
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch
+    import torch.distributed as dist
+    import orb_slam3_amd as ox
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(rank)
+    dist.init_process_group("gloo", rank=rank, world_size=world)   # only hands the RCCL id over
+    b = ox.shard_bounds(len(t), world)
+    dq = torch.from_numpy(q).cuda()
+    shard = torch.from_numpy(t[b[rank]:b[rank + 1]].copy()).cuda()
+    i, d = ox.knn_match2_sharded(dq, shard, b[rank])
+    torch.cuda.synchronize()
+    out[rank] = (i.cpu().numpy().view(np.uint32).copy(), d.cpu().numpy().view(np.uint16).copy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.needs_real_device
+def test_knn2_sharded_over_rccl_equals_unsharded(oracle):
+    """The sharded search on every GPU of the box (2 at least, else skipped): HIP kernels + one
+    RCCL all-gather + merge, one process per GPU, against the oracle's unsharded answer."""
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    world = min(torch.cuda.device_count(), 8)
+    if world < 2:
+        pytest.skip("needs 2 GPUs")
+    rng = np.random.default_rng(world)
+    t = rand_desc(rng, 2001)
+    t = np.repeat(t[:400], 6, axis=0)[:2001]          # duplicates across shard boundaries
+    q = t[rng.integers(0, len(t), 150)].copy()
+    q[::3] ^= rng.integers(0, 256, (50, 32), dtype=np.uint8) & 0x11
+    ridx, rdist = oracle.knn2(q, t)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = mp.Manager().dict()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_two_gpu_worker, args=(r, world, port, q, t, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert np.array_equal(out[r][0], ridx) and np.array_equal(out[r][1], rdist)
+
+
+@pytest.mark.needs_real_device
+def test_knn2_full_database_size_properties():
+    """1 M queries x 10 M train rows (1e13 pairs, the largest stated configuration; one pass
+    unsharded, one pass as 8 shards + merge): sharded == unsharded, planted rows found at
+    distance 0 at the lowest index that holds them, ordered neighbours, and a sample of queries
+    against numpy brute force."""
+    import ctypes as C
+    import torch
+    from orb_slam3_amd._lib import lib, check
+    g = torch.Generator(device="cuda").manual_seed(9)
+    nq, nt = 1_000_000, 10_000_000
+    t = torch.randint(0, 256, (nt, 32), dtype=torch.uint8, device="cuda", generator=g)
+    q = torch.randint(0, 256, (nq, 32), dtype=torch.uint8, device="cuda", generator=g)
+    t[nt - 5000:] = t[:5000]                    # duplicates in the first and the last shard
+    npl = nq // 10
+    src = torch.randint(0, nt, (npl,), device="cuda", generator=g)
+    q[:npl] = t[src]
+    flips = torch.randint(0, 256, (npl, 32), dtype=torch.uint8, device="cuda", generator=g) & 0x10
+    q[npl // 2:npl] ^= flips[npl // 2:]         # second half of the planted rows: up to 32 flipped bits
+
+    def run(tt, off, oi, od):
+        check(lib().orbx_knn2_device(C.c_void_p(q.data_ptr()), nq, C.c_void_p(tt.data_ptr()), tt.shape[0], off,
+                                     C.c_void_p(oi.data_ptr()), C.c_void_p(od.data_ptr()), None))
+    idx = torch.empty((nq, 2), dtype=torch.int32, device="cuda")
+    dst = torch.empty((nq, 2), dtype=torch.int16, device="cuda")
+    run(t, 0, idx, dst)
+    torch.cuda.synchronize()
+    shards = 8
+    b = orbx.shard_bounds(nt, shards)
+    pi = torch.empty((shards, nq, 2), dtype=torch.int32, device="cuda")
+    pd = torch.empty((shards, nq, 2), dtype=torch.int16, device="cuda")
+    for s in range(shards):
+        run(t[b[s]:b[s + 1]], b[s], pi[s], pd[s])
+    mi, md = torch.empty_like(idx), torch.empty_like(dst)
+    check(lib().orbx_top2_merge_device(C.c_void_p(pi.data_ptr()), C.c_void_p(pd.data_ptr()), shards, nq,
+                                       C.c_void_p(mi.data_ptr()), C.c_void_p(md.data_ptr()), None))
+    torch.cuda.synchronize()
+    assert torch.equal(mi, idx) and torch.equal(md, dst)
+    i_np = idx.cpu().numpy().view(np.uint32)
+    d_np = dst.cpu().numpy().view(np.uint16)
+    assert (d_np[:, 0] <= d_np[:, 1]).all() and (i_np[:, 0] != i_np[:, 1]).all()
+    assert (i_np < nt).all()
+    assert (d_np[: npl // 2, 0] == 0).all() and (d_np[npl // 2:npl, 0] <= 32).all()
+    src_np = src.cpu().numpy()
+    dup = src_np >= nt - 5000
+    want = np.where(dup, src_np - (nt - 5000), src_np)
+    hit = i_np[: npl // 2, 0]
+    assert (hit <= want[: npl // 2]).all()      # the planted row or an identical earlier one
+    t_np = t.cpu().numpy()
+    q_np = q.cpu().numpy()
+    lut = np.array([bin(i).count("1") for i in range(256)], np.uint16)
+    for qi in np.random.default_rng(1).integers(0, nq, 6):
+        d = lut[np.bitwise_xor(t_np, q_np[qi])].sum(axis=1, dtype=np.uint16)
+        best = np.flatnonzero(d <= np.partition(d, 1)[1])
+        order = best[np.lexsort((best, d[best]))][:2]
+        assert i_np[qi].tolist() == order.tolist() and d_np[qi].tolist() == d[order].tolist()

@@ -3,7 +3,7 @@ import ctypes as C, sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from orb_slam3_amd._lib import lib, check
-for nq, nt in [(4096, 65536), (65536, 262144), (131072, 1 << 20)]:
+for nq, nt in [(4096, 65536), (65536, 262144), (131072, 1 << 20), (1 << 20, 1250000)]:
     q = torch.randint(0, 256, (nq, 32), dtype=torch.uint8, device="cuda")
     t = torch.randint(0, 256, (nt, 32), dtype=torch.uint8, device="cuda")
     idx = torch.empty((nq, 2), dtype=torch.int32, device="cuda")
