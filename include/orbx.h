@@ -176,6 +176,21 @@ int orbx_knn2(int device_id, const uint8_t* q, int nq, const uint8_t* t, int64_t
  * database shard reports global indices. */
 int orbx_knn2_device(const uint8_t* d_q, int nq, const uint8_t* d_t, int64_t nt,
                      uint32_t index_offset, uint32_t* d_idx, uint16_t* d_dist, void* stream);
+/* orbx_knn2_device for callers that cannot allocate (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc): same
+ * arguments and results, but the per-segment partial results live in a fixed
+ * 64 MiB device array inside the library (one copy per GPU, held until the
+ * process ends) and no allocation routine is called.  No counterpart in the
+ * reference.  Limit: a scan of more than 4 194 304 train rows runs as
+ * s = ceil(nt / 4 194 304) segments at least, whose partial results take
+ * s * (nq * 12 + 512) bytes; a call for which that exceeds the array returns
+ * ORBX_ERR_SCRATCH (up to 4 194 304 train rows any nq fits).  Runs on the device
+ * that is current at the call (the stream's).  All calls on one GPU share the
+ * array: calls that overlap on one GPU (different streams or threads) race.
+ * The 4-byte aligned d_dist / 8-byte aligned d_idx of orbx_knn2_device apply. */
+int orbx_knn2_device_noalloc(const uint8_t* d_q, int nq, const uint8_t* d_t, int64_t nt,
+                             uint32_t index_offset, uint32_t* d_idx, uint16_t* d_dist, void* stream);
+size_t orbx_knn2_noalloc_scratch_bytes(void);
 /* Merge nparts partial 2-NN results (layout [part][nq][2]) into the global
  * 2-NN with the same (distance, index) ordering.  Device pointers; the index
  * array 8-byte and the distance array 4-byte aligned. */

@@ -83,6 +83,8 @@ SIGNATURES = {
     "orbx_hamming": (C.c_int, [_P, _P]),
     "orbx_knn2": (C.c_int, [C.c_int, _P, C.c_int, _P, C.c_int64, _P, _P]),
     "orbx_knn2_device": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_uint32, _P, _P, _P]),
+    "orbx_knn2_device_noalloc": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_uint32, _P, _P, _P]),
+    "orbx_knn2_noalloc_scratch_bytes": (C.c_size_t, []),
     "orbx_knn2_sharded": (C.c_int, [_P, _P, C.c_int, _P, C.c_int64, C.c_uint32, _P, _P, _P, C.c_size_t, _P]),
     "orbx_knn2_sharded_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "orbx_rccl_unique_id": (C.c_int, [_P]),

@@ -303,6 +303,53 @@ int orbx_knn2_device(const uint8_t* d_q, int nq, const uint8_t* d_t, int64_t nt,
   return knn2_launch(d_q, nq, d_t, nt, index_offset, d_idx, d_dist, (hipStream_t)stream);
 }
 
+// ---- the allocation-free form of orbx_knn2_device --------------------------------------------
+// Per-segment partial results live in a file-scope device array instead of stream-ordered
+// allocations.  Every GPU the library's code object is loaded on holds its own copy of the
+// array at its own address: host code never passes the array's name to a kernel, only the
+// address hipGetSymbolAddress returned for the device that is current at the call.
+#define ORBX_KNN2_SCRATCH_BYTES ((size_t)64 << 20)
+static __device__ __align__(256) uint8_t scratch[ORBX_KNN2_SCRATCH_BYTES];
+
+namespace {
+const int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+uint8_t* g_scratch_ptr[kMaxDevices] = {};
+
+// the current device's copy of `scratch`, looked up once per device
+int scratch_of_current_device(uint8_t** out) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return ORBX_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) return ORBX_ERR_HIP;
+    g_scratch_ptr[dev] = (uint8_t*)p;
+  }
+  *out = g_scratch_ptr[dev];
+  return ORBX_OK;
+}
+}  // namespace
+
+int orbx_knn2_device_noalloc(const uint8_t* d_q, int nq, const uint8_t* d_t, int64_t nt, uint32_t index_offset,
+                             uint32_t* d_idx, uint16_t* d_dist, void* stream) {
+  if (!knn2_args_ok(d_q, nq, d_t, nt, d_idx, d_dist)) return ORBX_ERR_BAD_ARG;
+  if (nq == 0) return ORBX_OK;
+  KnnCut c;
+  int st = knn2_cut(nq, nt, ORBX_KNN2_SCRATCH_BYTES, &c);
+  if (st != ORBX_OK) return st;
+  uint8_t* partial = nullptr;
+  if (c.segs > 1) {
+    st = scratch_of_current_device(&partial);
+    if (st != ORBX_OK) return st;
+  }
+  // every (segment, query) slot the merge reads is written by the scan of the same call, so
+  // nothing left in the array by an earlier call is ever read and nothing needs clearing
+  return knn2_enqueue(c, d_q, nq, d_t, nt, index_offset, d_idx, d_dist, partial, (hipStream_t)stream);
+}
+
+size_t orbx_knn2_noalloc_scratch_bytes(void) { return ORBX_KNN2_SCRATCH_BYTES; }
+
 int orbx_top2_merge_device(const uint32_t* d_idx_parts, const uint16_t* d_dist_parts, int nparts, int nq,
                            uint32_t* d_idx, uint16_t* d_dist, void* stream) {
   if (nparts < 1 || nq < 0 || (nq > 0 && (!d_idx_parts || !d_dist_parts || !d_idx || !d_dist)))
