@@ -1,23 +1,26 @@
 #!/usr/bin/env python3
-"""Throughput bench of the ORB extractor hot path on MI355X.
+"""Throughput bench of the ORB front-end hot path on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
 
 A step is one batched extraction (pyramid, FAST cells, quadtree, orientation,
 blur, descriptors) of `--batch` synthetic 752x480 frames that are already
-resident in HBM; outputs stay in HBM.  One process per GPU; for N > 1 launch
-through torch.distributed.run (RCCL is only used for the timing barrier: frames
-are independent, so the data path has no collective and scaling is weak).
-Rank 0 prints one JSON line.
+resident in HBM; outputs stay in HBM.  One process per GPU: with --gpus N > 1
+and no launcher around it, this script starts `torch.distributed.run` with N
+ranks as a child process and relays its output; under a launcher (RANK /
+WORLD_SIZE set) it is one of the ranks.  Frames are independent, so extraction
+has no collective (weak scaling; RCCL carries only the timing barrier); the
+sharded brute-force 2-NN leg is the one step with an exchange (one all-gather
+of top-2 records).  Rank 0 prints one JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -26,11 +29,14 @@ W, H = 752, 480
 PARAMS = (1000, 1.2, 8, 20, 7)   # nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST
 LAP = (0, 1000)                  # monocular call, core/src/Frame.cc:360
 HBM_PEAK_GBS = 8000.0
+VALU_PEAK_LANE_OPS = 256 * 64 * 2.4e9          # lane-ops/s: 256 CUs x 64 lanes x 2.4 GHz
+VALU_PEAK_WAVE_INSTS = 256 * 4 * 2.4e9 / 4     # wave instructions/s: 4 SIMDs per CU, 4 cycles each
 
 
 def level_sizes(w, h, nlevels, scale_factor):
+    import numpy as np
     sizes, s = [], np.float32(1.0)
-    for l in range(nlevels):
+    for _ in range(nlevels):
         inv = np.float32(1.0) / s
         sizes.append((int(np.rint(np.float32(w) * inv)), int(np.rint(np.float32(h) * inv))))
         s = np.float32(np.float64(s) * np.float64(np.float32(scale_factor)))
@@ -52,36 +58,55 @@ def algorithmic_bytes(w, h, nlevels, scale_factor, nkp):
 KERNEL_OF_STAGE = {"fast": "k_fast_cells", "blur": "k_blur"}
 
 
-def pmc_traffic(stage, batch):
-    """HBM-side bytes per launch of the stage's kernel(s) from the committed rocprofv3 counter
-    passes of this same command (FETCH_SIZE and WRITE_SIZE are collected in separate runs and
-    cannot be read from inside the process).  FETCH_SIZE is in KiB and, on gfx950, tallies the
-    128-byte requests of wide coalesced reads at 64 bytes, hence the factor 2; WRITE_SIZE KiB is
-    exact.  Returns None when no summary for this batch size is present."""
-    path = os.path.join(ROOT, "profiles", "r1_final_bench_b%d_pmc_summary.json" % batch)
-    if not os.path.exists(path):
-        return None, None
-    with open(path) as fh:
-        summ = json.load(fh)
-    for name, r in summ.items():
-        if name.startswith(KERNEL_OF_STAGE[stage]) and "FETCH_SIZE" in r and "WRITE_SIZE" in r:
-            return r["FETCH_SIZE"] * 2048.0 + r["WRITE_SIZE"] * 1024.0, os.path.relpath(path, ROOT)
-    return None, None
+def pmc_counters(stage, batch, two_pass):
+    """Per-launch counters of the stage's kernel from the newest committed rocprofv3 counter
+    summary of this same command whose recorded code state matches the running one (FETCH_SIZE,
+    WRITE_SIZE and the SQ counters are collected in separate runs and cannot be read from inside
+    the process).  FETCH_SIZE is in KiB and, on gfx950, tallies the 128-byte requests of wide
+    coalesced reads at 64 bytes, hence the factor 2; WRITE_SIZE KiB is exact.  Returns
+    (record or None, path or reason)."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_b%d_pmc_summary.json" % batch)),
+                   key=os.path.getmtime, reverse=True)
+    cands.sort(key=lambda p: os.path.basename(p), reverse=True)   # r2b > r2a > r1...
+    for path in cands:
+        with open(path) as fh:
+            summ = json.load(fh)
+        meta = summ.get("_meta", {})
+        if meta.get("fast_two_pass", None) != int(two_pass):
+            continue
+        for name, r in summ.items():
+            if name.startswith(KERNEL_OF_STAGE[stage]) and "FETCH_SIZE" in r and "WRITE_SIZE" in r:
+                return r, os.path.relpath(path, ROOT)
+    return None, "no counter summary under profiles/ matches this configuration"
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(frames, seconds_budget=15.0):
     """The CPU oracle (a restatement of the reference extractor; the reference itself needs
     OpenCV and cannot be built here) on this host's cores, one extractor per thread,
-    independent frames - the reference's thread-per-camera model (core/src/Frame.cc:151-154)."""
+    independent frames - the reference's thread-per-camera model (core/src/Frame.cc:151-154).
+    Threads: the CPU share of this job (OMP_NUM_THREADS where the box sets it - a GPU box shows
+    the whole machine's CPUs to every job - else the affinity mask)."""
     from tests import oracle_lib as O
-    import subprocess
     so = os.path.join(ROOT, "oracle", "liborb_oracle.so")
     if not os.path.exists(so):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
-    ncores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    ncores = int(os.environ.get("OMP_NUM_THREADS", "0")) or len(os.sched_getaffinity(0))
     ncores = max(1, min(ncores, len(os.sched_getaffinity(0))))
     # calibrate with one frame, then size the sample for ~seconds_budget of wall time
     ex = O.Extractor(*PARAMS)
+    ex.extract(frames[0], LAP)
     t0 = time.perf_counter()
     ex.extract(frames[0], LAP)
     one = time.perf_counter() - t0
@@ -103,48 +128,139 @@ def cpu_baseline(frames, seconds_budget=15.0):
     dt = time.perf_counter() - t0
     total = sum(done)
     return {"value": total / dt, "unit": "frames/s", "cores": ncores, "kind": "port",
+            "cpu_model": cpu_model(),
             "sample": "%d synthetic 752x480 frames on %d threads (%.1f s), CPU oracle "
-                      "oracle/orb_oracle.cpp -O2, one extractor per thread" % (total, ncores, dt),
+                      "oracle/orb_oracle.cpp (-O3 -march=x86-64-v3 -ffp-contract=off), one extractor per "
+                      "thread" % (total, ncores, dt),
+            "note": "a port of the reference's algorithm with scalar FAST; the reference's own OpenCV "
+                    "(SIMD FAST, resize, blur) would be faster, and is not installable here",
             "single_thread_ms_per_frame": one * 1e3}
 
 
-def hamming_bench(torch, orbx, dev, nq=65536, nt=262144, reps=3):
-    """Secondary metric: brute-force Hamming 2-NN pairs/s on device-resident descriptors
-    (uniform random 256-bit rows).  Roofline = VALU: 16 lane-ops per pair (8 xor + 8 bcnt)
-    against 256 CUs x 64 lanes x 2.4 GHz."""
+def hamming_bench(torch, orbx, dev, world, rank, nq=1 << 20, nt_per_gpu=1_250_000, reps=2):
+    """Brute-force Hamming 2-NN pairs/s at the largest stated configuration's per-GPU share:
+    1 M queries against 1.25 M train rows per GPU (10 M rows on 8 GPUs), uniform random 256-bit
+    rows, everything resident in HBM.  On one rank the plain device entry point; on N ranks the
+    sharded one (queries replicated, train rows sharded, one RCCL all-gather of the top-2
+    records, merge).  Roofline = VALU: 16 lane-ops per pair (8 xor + 8 bcnt)."""
     import ctypes as C
     from orb_slam3_amd._lib import lib, check
-    q = torch.randint(0, 256, (nq, 32), dtype=torch.uint8, device=dev)
-    t = torch.randint(0, 256, (nt, 32), dtype=torch.uint8, device=dev)
-    idx = torch.empty((nq, 2), dtype=torch.int32, device=dev)
-    dst = torch.empty((nq, 2), dtype=torch.int16, device=dev)
+    g = torch.Generator(device=dev).manual_seed(1234)
+    q = torch.randint(0, 256, (nq, 32), dtype=torch.uint8, device=dev, generator=g)
+    g.manual_seed(99 + rank)
+    t = torch.randint(0, 256, (nt_per_gpu, 32), dtype=torch.uint8, device=dev, generator=g)
+    offset = rank * nt_per_gpu
     stream = torch.cuda.current_stream(dev).cuda_stream
+    if world > 1:
+        import torch.distributed as dist
 
-    def run():
-        check(lib().orbx_knn2_device(C.c_void_p(q.data_ptr()), nq, C.c_void_p(t.data_ptr()), nt, 0,
-                                     C.c_void_p(idx.data_ptr()), C.c_void_p(dst.data_ptr()),
-                                     C.c_void_p(stream)))
+        def run():
+            return orbx.knn_match2_sharded(q, t, offset)
+    else:
+        idx = torch.empty((nq, 2), dtype=torch.int32, device=dev)
+        dst = torch.empty((nq, 2), dtype=torch.int16, device=dev)
+
+        def run():
+            check(lib().orbx_knn2_device(C.c_void_p(q.data_ptr()), nq, C.c_void_p(t.data_ptr()), nt_per_gpu,
+                                         offset, C.c_void_p(idx.data_ptr()), C.c_void_p(dst.data_ptr()),
+                                         C.c_void_p(stream)))
     run()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
     for _ in range(reps):
         run()
-    e1.record()
     torch.cuda.synchronize()
-    sec = e0.elapsed_time(e1) * 1e-3 / reps
-    pairs = nq * nt / sec
-    peak_ops = 256 * 64 * 2.4e9
-    return {"metric": "Hamming pairs/s (brute-force 2-NN)", "value": pairs, "unit": "pairs/s",
-            "queries": nq, "train": nt, "ms": sec * 1e3,
-            "roofline": {"bound": "valu", "achieved": pairs * 16 / 1e12, "peak": peak_ops / 1e12,
-                         "unit": "T lane-ops/s", "frac": pairs * 16 / peak_ops}}
+    sec = (time.perf_counter() - t0) / reps
+    if world > 1:
+        tt = torch.tensor([sec], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        sec = float(tt.item())
+    pairs = nq * nt_per_gpu * world / sec
+    out = {"metric": "Hamming pairs/s (brute-force 2-NN, train rows sharded over the GPUs)",
+           "value": pairs, "unit": "pairs/s", "queries": nq, "train_rows_total": nt_per_gpu * world,
+           "train_rows_per_gpu": nt_per_gpu, "ms": sec * 1e3, "n_gpus": world,
+           "roofline": {"bound": "valu", "achieved": pairs * 16 / 1e12, "peak": VALU_PEAK_LANE_OPS * world / 1e12,
+                        "unit": "T lane-ops/s", "frac": pairs * 16 / (VALU_PEAK_LANE_OPS * world)}}
+    if world > 1:
+        out["exchange"] = {"collective": "ncclAllGather (in place)", "bytes_per_rank_sent": nq * 12,
+                           "bytes_per_rank_received": nq * 12 * world}
+    return out
+
+
+def host_path_bench(torch, orbx, dev, local_rank, frames, n_frames=2048):
+    """The interval the reference instruments as "ORB ext" (core/src/Frame.cc:147-161): images in
+    host memory -> keypoints and descriptors in host memory, PCIe both ways included.  Batches
+    through orbx_extract_batch with ordinary (pageable) and with page-locked caller memory, and the
+    blocking single-frame call orbx_extract.  Never the headline value."""
+    import ctypes as C
+    import numpy as np
+    from orb_slam3_amd._lib import lib, check, KEYPOINT_DTYPE
+    ex = orbx.ORBextractor(*PARAMS, device=local_rank, max_batch=n_frames)
+    cap = ex.max_keypoints()
+    i32p = C.POINTER(C.c_int32)
+    n = np.zeros(n_frames, np.int32)
+    mono = np.zeros(n_frames, np.int32)
+    reps = (n_frames + len(frames) - 1) // len(frames)
+    src = np.tile(frames, (reps, 1, 1))[:n_frames]
+    out = {"frames_per_call": n_frames,
+           "interval": "host images in -> host keypoints + descriptors out (PCIe included), core/src/Frame.cc:147-161"}
+
+    def timed(imgs, kps, desc, label):
+        ptrs = (C.c_void_p * n_frames)(*[imgs[i].ctypes.data for i in range(n_frames)])
+
+        def call():
+            check(lib().orbx_extract_batch(ex._h, n_frames, ptrs, W, H, W, LAP[0], LAP[1],
+                                           kps.ctypes.data_as(C.c_void_p), desc.ctypes.data_as(C.c_void_p), cap,
+                                           n.ctypes.data_as(i32p), mono.ctypes.data_as(i32p)), "orbx_extract_batch")
+        call()
+        best = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            call()
+            best = min(best, time.perf_counter() - t0)
+        out[label] = {"frames_per_s": n_frames / best, "ms_per_call": best * 1e3,
+                      "keypoints_per_frame": float(n.mean())}
+
+    # ordinary memory both ways
+    kps = np.zeros((n_frames, cap), KEYPOINT_DTYPE)
+    desc = np.zeros((n_frames, cap, 32), np.uint8)
+    timed(np.ascontiguousarray(src), kps, desc, "pageable")
+    # page-locked memory both ways
+    pin_i = torch.empty((n_frames, H, W), dtype=torch.uint8).pin_memory()
+    pin_k = torch.empty((n_frames, cap * 28), dtype=torch.uint8).pin_memory()
+    pin_d = torch.empty((n_frames, cap, 32), dtype=torch.uint8).pin_memory()
+    pi = pin_i.numpy()
+    pi[:] = src
+    timed(pi, pin_k.numpy(), pin_d.numpy(), "pinned")
+    # single-frame blocking call (the drop-in SLAM caller)
+    ex1 = orbx.ORBextractor(*PARAMS, device=local_rank)
+    k1 = np.zeros(cap, KEYPOINT_DTYPE)
+    d1 = np.zeros((cap, 32), np.uint8)
+    n1, m1 = C.c_int32(), C.c_int32()
+    img = np.ascontiguousarray(frames[0])
+
+    def one():
+        check(lib().orbx_extract(ex1._h, C.c_void_p(img.ctypes.data), W, H, W, LAP[0], LAP[1],
+                                 k1.ctypes.data_as(C.c_void_p), d1.ctypes.data_as(C.c_void_p), cap,
+                                 C.byref(n1), C.byref(m1)), "orbx_extract")
+    for _ in range(5):
+        one()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        one()
+    out["single_frame_ms"] = (time.perf_counter() - t0) / 50 * 1e3
+    ex.close()
+    ex1.close()
+    return out
 
 
 def stereo_bench(torch, orbx, dev, local_rank, batch=128, reps=5):
     """Secondary metric: rectified stereo pairs/s (config: 752x480, 1200 kp per camera,
     vLappingArea (0,0)): both extractions plus the device-resident ComputeStereoMatches
     (band search, L1 refinement, depth, median rule), images resident in HBM."""
+    import numpy as np
     params = (1200, 1.2, 8, 20, 7)
     distinct = 8
     lefts = [orbx.textured_frame(500 + i, W, H) for i in range(distinct)]
@@ -177,9 +293,83 @@ def stereo_bench(torch, orbx, dev, local_rank, batch=128, reps=5):
     exl.sync()
     sec_match = (time.perf_counter() - t0) / reps
     nmatch = float(np.mean([(orbx.stereo_download(exl, f)[1] > 0).sum() for f in range(min(batch, 8))]))
-    return {"metric": "stereo pairs/s @752x480, 2x1200kp, extraction + ComputeStereoMatches",
-            "value": batch / sec, "unit": "pairs/s", "pairs_per_step": batch, "ms_per_step": sec * 1e3,
-            "match_stage_ms_per_step": sec_match * 1e3, "matches_per_pair": nmatch}
+    res = {"metric": "stereo pairs/s @752x480, 2x1200kp, extraction + ComputeStereoMatches",
+           "value": batch / sec, "unit": "pairs/s", "pairs_per_step": batch, "ms_per_step": sec * 1e3,
+           "match_stage_ms_per_step": sec_match * 1e3, "matches_per_pair": nmatch}
+    exl.close()
+    exr.close()
+    return res
+
+
+def fisheye_bench(torch, orbx, dev, local_rank, batch=128, reps=5):
+    """Secondary metric: fisheye stereo pairs/s (config: 512x512 pair, 1500 kp per camera, lapping
+    areas): both extractions for the whole batch, then per pair the brute-force 2-NN of the left
+    lapping-area descriptors against the right ones (core/src/Frame.cc:1159-1177), indices and
+    distances back on the host."""
+    import numpy as np
+    params = (1500, 1.2, 8, 20, 7)
+    S, distinct = 512, 8
+    lefts = [orbx.textured_frame(800 + i, S, S) for i in range(distinct)]
+    rights = [np.roll(l, 9, axis=1) for l in lefts]
+    reps_t = (batch + distinct - 1) // distinct
+    dl = torch.from_numpy(np.tile(np.stack(lefts), (reps_t, 1, 1))[:batch].copy()).to(dev)
+    dr = torch.from_numpy(np.tile(np.stack(rights), (reps_t, 1, 1))[:batch].copy()).to(dev)
+    exl = orbx.ORBextractor(*params, device=local_rank, max_batch=batch)
+    exr = orbx.ORBextractor(*params, device=local_rank, max_batch=batch)
+    lap_l, lap_r = (100, 511), (0, 400)
+
+    def extract():
+        exl.extract_batch_device(dl.data_ptr(), batch, S, S, S, lap_l)
+        exr.extract_batch_device(dr.data_ptr(), batch, S, S, S, lap_r)
+    extract()
+    exl.sync()
+    exr.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        extract()
+    exl.sync()
+    exr.sync()
+    sec_ext = (time.perf_counter() - t0) / reps
+    nm = min(batch, 32)
+    t0 = time.perf_counter()
+    nq = 0
+    for f in range(nm):
+        idx, dist, ml, mr = orbx.lapping_knn_match2(exl, exr, f)
+        nq += len(idx)
+    sec_knn = (time.perf_counter() - t0) / nm
+    res = {"metric": "fisheye stereo pairs/s @512x512, 2x1500kp, lapping areas: extraction (batched) + "
+                     "lapping-area 2-NN (per pair, results on the host)",
+           "value": 1.0 / (sec_ext / batch + sec_knn), "unit": "pairs/s",
+           "extraction_ms_per_pair": sec_ext / batch * 1e3, "lapping_knn2_ms_per_pair": sec_knn * 1e3,
+           "lapping_queries_per_pair": nq / nm}
+    exl.close()
+    exr.close()
+    return res
+
+
+def kitti_bench(torch, orbx, dev, local_rank, batch=256, reps=5):
+    """Secondary metric: frames/s at 1241x376, 2000 kp, 8 levels (the batched stereo configuration's
+    per-camera extraction), images resident in HBM."""
+    import numpy as np
+    w, h, distinct = 1241, 376, 8
+    params = (2000, 1.2, 8, 20, 7)
+    imgs = np.stack([orbx.textured_frame(300 + i, w, h) for i in range(distinct)])
+    d = torch.from_numpy(np.tile(imgs, ((batch + distinct - 1) // distinct, 1, 1))[:batch].copy()).to(dev)
+    ex = orbx.ORBextractor(*params, device=local_rank, max_batch=batch)
+    ex.extract_batch_device(d.data_ptr(), batch, w, h, w, (0, 0))
+    ex.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ex.extract_batch_device(d.data_ptr(), batch, w, h, w, (0, 0))
+    ex.sync()
+    sec = (time.perf_counter() - t0) / reps
+    nkp = float(np.mean([len(ex.download(f)[1]) for f in range(4)]))
+    _, frame_bytes = algorithmic_bytes(w, h, params[2], params[1], int(round(nkp)))
+    res = {"metric": "ORB frames/s @1241x376,2000kp,8lvl", "value": batch / sec, "unit": "frames/s",
+           "frames_per_step": batch, "ms_per_step": sec * 1e3, "keypoints_per_frame": nkp,
+           "whole_frame_roofline_frac": batch / sec * frame_bytes / (HBM_PEAK_GBS * 1e9)}
+    ex.close()
+    return res
 
 
 def _bench_vocabulary(orbx, local_rank, k=10, depth=5):
@@ -191,6 +381,7 @@ def _bench_vocabulary(orbx, local_rank, k=10, depth=5):
 
 def bow_bench(torch, orbx, dev, local_rank, batch=256, reps=5, k=10, depth=5):
     """Secondary metric (opt-in): frames/s of Frame::ComputeBoW on device-resident descriptors."""
+    import numpy as np
     voc, _ = _bench_vocabulary(orbx, local_rank, k, depth)
     distinct = 8
     imgs = np.stack([orbx.textured_frame(700 + i, W, H) for i in range(distinct)])
@@ -215,6 +406,7 @@ def guided_bench(torch, orbx, dev, local_rank, reps=20):
     """Secondary metric (opt-in): latency of one SearchByProjection(CurrentFrame, LastFrame) call
     (host arrays in, assignments out) on a 752x480 frame with 1000 features, last frame = the same
     scene shifted by 6 pixels."""
+    import numpy as np
     shift = 6
     wide = orbx.textured_frame(41, W + shift, H)
     a, b = np.ascontiguousarray(wide[:, shift:]), np.ascontiguousarray(wide[:, :W])
@@ -261,6 +453,45 @@ def guided_bench(torch, orbx, dev, local_rank, reps=20):
             "by_bow": {"ms": secb * 1e3, "keyframe_features": len(ka), "nodes": len(an), "matches": nmb}}
 
 
+def spawn_ranks(n):
+    """Not under a launcher: start one rank per GPU with torch.distributed.run as a child process
+    (this process has not touched torch or HIP) and exit with its status."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run_cpu(args):
+    """Launcher plumbing without a GPU (tests): rendezvous over gloo, the barrier and the
+    max-over-ranks reduction of the timed loop, the shard layout of the 2-NN leg, and rank 0's
+    JSON line.  No part of the hot path runs, so the line carries no value."""
+    import torch
+    import torch.distributed as dist
+    from orb_slam3_amd.matcher import shard_bounds
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group("gloo")
+        dist.barrier()
+    t = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    b = shard_bounds(10_000_000, world)
+    if rank == 0:
+        print(json.dumps({"metric": "ORB frames/s @752x480,1000kp,8lvl", "value": None, "unit": "frames/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True,
+                          "max_over_ranks_s": float(t.item()), "shard_bounds": b}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -268,16 +499,25 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024, help="frames per step per GPU")
     ap.add_argument("--no-match", action="store_true", help="skip the Hamming 2-NN leg")
-    ap.add_argument("--stereo", action="store_true",
-                    help="add the stereo leg (752x480 pairs, 2x1200 kp: both extractions + ComputeStereoMatches)")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the secondary legs (host path, stereo, fisheye, 1241x376)")
+    ap.add_argument("--stereo", action="store_true", help="kept for older command lines: the stereo leg is on by default")
     ap.add_argument("--bow", action="store_true", help="add the bag-of-words leg (frames/s of ComputeBoW)")
     ap.add_argument("--guided", action="store_true", help="add the guided-matching leg (ms per SearchByProjection call)")
     ap.add_argument("--distinct", type=int, default=32, help="distinct synthetic frames (tiled to the batch)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--stage-times", action="store_true",
                     help="also time every stage serialised on one stream (whole batch per launch)")
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="launcher plumbing only, over gloo, without a GPU (used by the tests)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+    if args.dry_run_cpu:
+        return dry_run_cpu(args)
+
+    import numpy as np
     import torch
     import torch.distributed as dist
     import orb_slam3_amd as orbx
@@ -352,13 +592,22 @@ def main():
     ex.sync()
     nkp = float(np.mean([len(ex.download(f)[1]) for f in range(min(B, 8))]))
 
+    out = None
     if rank == 0:
         stage_bytes, frame_bytes = algorithmic_bytes(W, H, PARAMS[2], PARAMS[1], int(round(nkp)))
         fps = world * B * args.steps / dt
         dom = "fast"
         bytes_per_launch = stage_bytes[dom] * det_frames_per_launch
         achieved = bytes_per_launch / (det_ms_per_launch * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(dom, B)
+        two_pass = os.environ.get("ORBX_FAST_SINGLE_PASS", "0") != "1"
+        pmc, pmc_src = pmc_counters(dom, B, two_pass)
+        traffic = pmc["FETCH_SIZE"] * 2048.0 + pmc["WRITE_SIZE"] * 1024.0 if pmc else None
+        valu = None
+        if pmc and "SQ_INSTS_VALU" in pmc:
+            rate = pmc["SQ_INSTS_VALU"] / (det_ms_per_launch * 1e-3)
+            valu = {"wave_insts_per_launch": pmc["SQ_INSTS_VALU"], "insts_per_cell_wave": pmc.get("valu_per_wave"),
+                    "achieved": rate / 1e9, "peak": VALU_PEAK_WAVE_INSTS / 1e9, "unit": "G wave-insts/s",
+                    "frac": rate / VALU_PEAK_WAVE_INSTS}
         out = {
             "metric": "ORB frames/s @752x480,1000kp,8lvl",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -371,24 +620,47 @@ def main():
                        "keypoints_per_frame": nkp, "parallelism": "frames sharded, no collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": traffic_src,
+                         "traffic_source": pmc_src,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "algorithmic_bytes_per_frame": stage_bytes[dom],
-                         "launch_ms": det_ms_per_launch, "frames_per_launch": det_frames_per_launch},
+                         "launch_ms": det_ms_per_launch, "frames_per_launch": det_frames_per_launch,
+                         "true_bound": "valu: the kernel's limiter is VALU issue, not HBM (see valu)",
+                         "valu": valu},
             "stage_ms_per_step_serialised": acc or None,
             "whole_frame_roofline_frac": fps / world * frame_bytes / (HBM_PEAK_GBS * 1e9),
         }
-        if not args.no_match:
-            out["hamming"] = hamming_bench(torch, orbx, dev)
-        if args.stereo:
-            out["stereo"] = stereo_bench(torch, orbx, dev, local_rank)
+    ex.close()
+    del d_imgs
+    # the 2-NN leg runs on every rank (sharded when there are several)
+    if not args.no_match:
+        try:
+            ham = hamming_bench(torch, orbx, dev, world, rank)
+        except Exception as e:   # the headline line must not be lost to a failure of a secondary leg
+            ham = {"error": "%s: %s" % (type(e).__name__, e)}
+        if out is not None:
+            out["hamming"] = ham
+    if rank == 0:
+        extra = not args.no_extra and world == 1
+        legs = []
+        if extra:
+            legs += [("host_path", lambda: host_path_bench(torch, orbx, dev, local_rank, frames)),
+                     ("stereo", lambda: stereo_bench(torch, orbx, dev, local_rank)),
+                     ("fisheye", lambda: fisheye_bench(torch, orbx, dev, local_rank)),
+                     ("kitti", lambda: kitti_bench(torch, orbx, dev, local_rank))]
+        elif args.stereo:
+            legs.append(("stereo", lambda: stereo_bench(torch, orbx, dev, local_rank)))
         if args.bow:
-            out["bow"] = bow_bench(torch, orbx, dev, local_rank)
+            legs.append(("bow", lambda: bow_bench(torch, orbx, dev, local_rank)))
         if args.guided:
-            out["guided"] = guided_bench(torch, orbx, dev, local_rank)
+            legs.append(("guided", lambda: guided_bench(torch, orbx, dev, local_rank)))
+        for name, fn in legs:
+            try:
+                out[name] = fn()
+            except Exception as e:
+                out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames)
-            out["gpu_over_cpu"] = fps / out["cpu_baseline"]["value"]
+            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

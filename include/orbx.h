@@ -93,10 +93,21 @@ int orbx_pyramid(orbx_extractor* ex, int level, const uint8_t** padded, int* wid
                  int* stride);
 
 /* Batched operator(): n_frames equally sized host images -> per-frame outputs.
- * kps/desc hold n_frames*cap entries, frame f at offset f*cap. */
+ * kps/desc hold n_frames*cap entries, frame f at offset f*cap.  The batch runs
+ * as groups of up to 128 frames whose transfers in, kernels and transfers out
+ * overlap.  Images and result arrays in page-locked host memory
+ * (orbx_host_alloc, hipHostMalloc, hipHostRegister) are read and written by the
+ * copy engines directly - then entries of a frame beyond its n_out are
+ * unspecified; ordinary memory goes through pinned staging filled by a few
+ * host threads (ORBX_HOST_THREADS, default 6). */
 int orbx_extract_batch(orbx_extractor* ex, int n_frames, const uint8_t* const* imgs, int width,
                        int height, int stride, int lap0, int lap1, orbx_keypoint* kps,
                        uint8_t* desc, int cap, int* n_out, int* mono_out);
+
+/* Page-locked host memory (hipHostMalloc / hipHostFree) for images and results
+ * of the host-pointer entry points, for callers that do not link HIP. */
+int orbx_host_alloc(size_t bytes, void** out);
+int orbx_host_free(void* p);
 
 /* Device-resident batched operator(): d_imgs points at n_frames contiguous
  * images (height*stride bytes each) in device memory.  Work is enqueued on the

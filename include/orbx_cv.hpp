@@ -50,9 +50,14 @@ class ORBextractor {
  public:
   enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };
 
+  // hostPyramid: fill mvImagePyramid inside operator() as the reference does (extractor.cc:1030,
+  // 1111-1112), so that unchanged callers such as Frame::ComputeStereoMatches (core/src/Frame.cc:
+  // 837, 921-941) can read it right after the call.  Callers that keep the stereo association on
+  // the device (ComputeStereoMatches below) pass false and save the 1.3 MB transfer per call;
+  // they can still fetch the pyramid later with SyncImagePyramid().
   ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST,
-               int device = 0)
-      : nfeatures_(nfeatures), scaleFactor_(scaleFactor), nlevels_(nlevels) {
+               int device = 0, bool hostPyramid = true)
+      : nfeatures_(nfeatures), scaleFactor_(scaleFactor), nlevels_(nlevels), hostPyramid_(hostPyramid) {
     orbx_params p;
     p.nfeatures = nfeatures;
     p.scale_factor = scaleFactor;
@@ -101,6 +106,8 @@ class ORBextractor {
         std::copy(scratchDesc_.begin() + (size_t)i * 32, scratchDesc_.begin() + (size_t)(i + 1) * 32, d.ptr(i));
     }
     pyramidFresh_ = false;
+    if (hostPyramid_) SyncImagePyramid();
+    else for (cv::Mat& m : mvImagePyramid) m = cv::Mat();   // no stale views of the previous frame
     return mono;
   }
 
@@ -111,10 +118,10 @@ class ORBextractor {
   std::vector<float> GetScaleSigmaSquares() { return mvLevelSigma2_; }
   std::vector<float> GetInverseScaleSigmaSquares() { return mvInvLevelSigma2_; }
 
-  // Level images as ROI views (19-pixel border around each, extractor.cc:1103-1127).  The
-  // reference fills this member inside operator(); here the planes stay on the device until
-  // somebody asks, so callers that read it call SyncImagePyramid() first.  Device-side
-  // consumers (ComputeStereoMatches below) never need it.
+  // Level images as ROI views (19-pixel border around each, extractor.cc:1103-1127) into a
+  // page-locked host mirror that the next operator() overwrites, as the reference overwrites its
+  // pyramid.  Filled by operator() unless the extractor was built with hostPyramid = false; then
+  // the planes stay on the device until SyncImagePyramid() is called.
   std::vector<cv::Mat> mvImagePyramid;
   void SyncImagePyramid() {
     if (pyramidFresh_) return;
@@ -135,6 +142,7 @@ class ORBextractor {
   int nfeatures_;
   double scaleFactor_;   // the reference keeps the float argument in a double (extractor.h:89)
   int nlevels_;
+  bool hostPyramid_ = true;
   bool pyramidFresh_ = false;
   std::vector<uint8_t> scratchDesc_;
   std::vector<int> mnFeaturesPerLevel_;

@@ -65,6 +65,8 @@ SIGNATURES = {
     "orbx_pyramid": (C.c_int, [_P, C.c_int, C.POINTER(_P), _i32p, _i32p, _i32p]),
     "orbx_extract_batch": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_int, _P, _P, C.c_int, _i32p, _i32p]),
+    "orbx_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(_P)]),
+    "orbx_host_free": (C.c_int, [_P]),
     "orbx_extract_batch_device": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "orbx_sync": (C.c_int, [_P]),
     "orbx_batch_results_device": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P),

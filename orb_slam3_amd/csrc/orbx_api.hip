@@ -8,7 +8,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "../../include/orbx.h"
@@ -114,6 +119,87 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 }  // namespace
 
+namespace {
+// A few host threads that copy image rows into pinned staging and results out of it while the
+// GPU works on the neighbouring group of frames (one memcpy thread moves ~10 GB/s, a frame is
+// 0.36 MB in and 0.06 MB out).  Only the host-pointer batch entry point with pageable caller
+// memory uses it; it is created on first use.
+class HostPool {
+ public:
+  explicit HostPool(int nthreads) {
+    for (int i = 0; i < nthreads; ++i) workers_.emplace_back([this] { loop(); });
+  }
+  ~HostPool() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto& t : workers_) t.join();
+  }
+  // fn(i) for i in [0, n), on the workers and the calling thread; returns when all are done
+  void parallel_for(int n, const std::function<void(int)>& fn) {
+    if (n <= 0) return;
+    if (n == 1 || workers_.empty()) {
+      for (int i = 0; i < n; ++i) fn(i);
+      return;
+    }
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      fn_ = &fn; n_ = n; next_.store(0); done_ = 0; ++epoch_;
+    }
+    cv_.notify_all();
+    work();
+    std::unique_lock<std::mutex> lk(mu_);
+    idle_.wait(lk, [this] { return done_ == n_; });
+    fn_ = nullptr;
+  }
+
+ private:
+  void work() {
+    int mine = 0;
+    const std::function<void(int)>* fn;
+    int n;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      fn = fn_; n = n_;
+    }
+    if (!fn) return;
+    for (;;) {
+      const int i = next_.fetch_add(1);
+      if (i >= n) break;
+      (*fn)(i);
+      ++mine;
+    }
+    if (mine) {
+      std::lock_guard<std::mutex> lk(mu_);
+      done_ += mine;
+      if (done_ == n_) idle_.notify_all();
+    }
+  }
+  void loop() {
+    unsigned seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return stop_ || epoch_ != seen; });
+        if (stop_) return;
+        seen = epoch_;
+      }
+      work();
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex mu_;
+  std::condition_variable cv_, idle_;
+  const std::function<void(int)>* fn_ = nullptr;
+  int n_ = 0, done_ = 0;
+  std::atomic<int> next_{0};
+  unsigned epoch_ = 0;
+  bool stop_ = false;
+};
+}  // namespace
+
 struct orbx_extractor {
   orbx_params prm;
   double scaleFactorD;  // the reference keeps the float argument in a double member
@@ -179,16 +265,20 @@ struct orbx_extractor {
   void* d_bowBlock = nullptr;
   int bowFrames = 0;
 
-  // pinned host staging
-  // pinned host staging for the host-pointer entry points: two input buffers of stageFrames
-  // images each (filled by the CPU while the other one is in flight) and one output buffer
+  // Host-pointer entry points: a batch runs as groups of groupFrames frames, each group's
+  // transfer in, kernels and transfer out on streams of their own, so that the transfer in of
+  // group k+1 and the transfer out of group k-1 overlap the kernels of group k.  Pinned staging
+  // (two buffers each way, allocated on first use) only serves pageable caller memory.
+  int groupFrames = 0;
+  hipStream_t sIn = nullptr, sOut = nullptr;
   uint8_t* h_in[2] = {nullptr, nullptr};
-  uint8_t* h_out = nullptr;
-  int stageFrames = 0;
-  hipEvent_t evIn[2] = {nullptr, nullptr};
-  bool evInUsed[2] = {false, false};
-  std::vector<uint8_t> h_pyr;       // lazily downloaded pyramid of frame 0
-  std::vector<char> h_pyr_valid;
+  uint8_t* h_out[2] = {nullptr, nullptr};
+  int* h_cnt[2] = {nullptr, nullptr};      // n and mono of a group (pinned), 2 * groupFrames ints
+  hipEvent_t evIn[2] = {nullptr, nullptr}, evComp[2] = {nullptr, nullptr}, evOut[2] = {nullptr, nullptr};
+  HostPool* pool = nullptr;
+  uint8_t* h_pyr = nullptr;         // pinned host mirror of frame 0's pyramid, all levels back to back
+  size_t h_pyr_bytes = 0;
+  bool h_pyr_valid = false;
 
   int lastFrames = 0;
   bool profiling = false;
@@ -204,6 +294,10 @@ struct orbx_extractor {
   int buildPlan(int W, int H);
   void freePlan();
   int run(const uint8_t* d_images, int istride, size_t iframe, int nframes, int lap0, int lap1);
+  int enqueuePart(int pk, hipStream_t m, hipStream_t side, hipEvent_t fork, hipEvent_t join, int f0, int n,
+                  hipEvent_t pyrDone, const uint8_t* d_images, int istride, size_t iframe, int lap0, int lap1);
+  void afterExtraction(int nframes);
+  int ensureHostStaging(bool pageableIn, bool pageableOut);
 };
 
 void orbx_extractor::buildTables() {
@@ -263,9 +357,14 @@ void orbx_extractor::freePlan() {
   for (void* b : bufs) if (b) (void)hipFree(b);
   dp = nullptr; d_img = d_pyr = d_blur = d_desc = nullptr; d_cand = d_flatA = d_flatB = d_sel = nullptr;
   d_cellCount = d_selCount = d_n = d_mono = nullptr; d_octws = nullptr; d_kps = nullptr; d_work = nullptr;
-  for (int i = 0; i < 2; ++i) { if (h_in[i]) (void)hipHostFree(h_in[i]); h_in[i] = nullptr; evInUsed[i] = false; }
-  if (h_out) (void)hipHostFree(h_out);
-  h_out = nullptr; stageFrames = 0;
+  for (int i = 0; i < 2; ++i) {
+    if (h_in[i]) (void)hipHostFree(h_in[i]);
+    if (h_out[i]) (void)hipHostFree(h_out[i]);
+    if (h_cnt[i]) (void)hipHostFree(h_cnt[i]);
+    h_in[i] = h_out[i] = nullptr; h_cnt[i] = nullptr;
+  }
+  if (h_pyr) (void)hipHostFree(h_pyr);
+  h_pyr = nullptr; h_pyr_bytes = 0; h_pyr_valid = false;
   planned = false;
 }
 
@@ -523,12 +622,30 @@ int orbx_extractor::buildPlan(int W, int H) {
   HIP_TRY(hipMalloc((void**)&d_work, (size_t)B * hp.kp_cap * sizeof(WorkItem)));
   HIP_TRY(hipMalloc((void**)&d_n, (size_t)B * 4));
   HIP_TRY(hipMalloc((void**)&d_mono, (size_t)B * 4));
-  stageFrames = std::min(B, 16);
-  for (int i = 0; i < 2; ++i)
-    HIP_TRY(hipHostMalloc((void**)&h_in[i], (size_t)stageFrames * W * H, hipHostMallocDefault));
-  HIP_TRY(hipHostMalloc((void**)&h_out, (size_t)stageFrames * (hp.kp_cap * 60 + 8), hipHostMallocDefault));
-  h_pyr.clear();
-  h_pyr_valid.assign(nl, 0);
+  // frames per group of the host-pointer path: large enough for full-rate kernels, small enough
+  // that two groups of pinned staging stay modest (64 MB of images per buffer at most)
+  groupFrames = (int)std::max<size_t>(1, std::min<size_t>({(size_t)B, (size_t)128, ((size_t)64 << 20) / ((size_t)W * H)}));
+  if (const char* e = std::getenv("ORBX_HOST_GROUP")) {   // timing / test knob, results do not change
+    const long g = std::strtol(e, nullptr, 10);
+    if (g >= 1 && g <= B) groupFrames = (int)g;
+  }
+  return ORBX_OK;
+}
+
+int orbx_extractor::ensureHostStaging(bool pageableIn, bool pageableOut) {
+  const int G = groupFrames;
+  for (int i = 0; i < 2; ++i) {
+    if (!h_cnt[i]) HIP_TRY(hipHostMalloc((void**)&h_cnt[i], (size_t)G * 8, hipHostMallocDefault));
+    if (pageableIn && !h_in[i])
+      HIP_TRY(hipHostMalloc((void**)&h_in[i], (size_t)G * hp.W * hp.H, hipHostMallocDefault));
+    if (pageableOut && !h_out[i])
+      HIP_TRY(hipHostMalloc((void**)&h_out[i], (size_t)G * hp.kp_cap * 60, hipHostMallocDefault));
+  }
+  if ((pageableIn || pageableOut) && !pool && G > 1) {
+    int nt = 6;
+    if (const char* e = std::getenv("ORBX_HOST_THREADS")) nt = std::min(std::max(std::atoi(e), 1), 64);
+    pool = new (std::nothrow) HostPool(nt - 1);   // the calling thread works too
+  }
   return ORBX_OK;
 }
 
@@ -563,25 +680,6 @@ int orbx_extractor::run(const uint8_t* d_images, int istride, size_t iframe, int
     // overlaps the VALU-bound detection of the part before it, and its detection overlaps
     // that part's quadtree and descriptors.
     const int nparts = std::max(1, std::min(kMaxParts, nframes / kSplitMin));
-    auto part = [&](int pk, hipStream_t m, hipStream_t side, hipEvent_t fork, hipEvent_t join, int f0, int n,
-                    hipEvent_t pyrDone) -> int {
-      orbx::launch_pyramid(hp, d_images, istride, iframe, d_pyr, f0, n, m);
-      if (pyrDone) HIP_TRY(hipEventRecord(pyrDone, m));
-      HIP_TRY(hipEventRecord(evDet[pk][0], m));
-      orbx::launch_fast(hp, dp, d_pyr, d_cand, d_cellCount, 0, hp.nlevels, f0, n, m);
-      HIP_TRY(hipEventRecord(evDet[pk][1], m));
-      detFrames[pk] = n;
-      HIP_TRY(hipEventRecord(fork, m));
-      HIP_TRY(hipStreamWaitEvent(side, fork, 0));
-      orbx::launch_blur(hp, dp, d_pyr, d_blur, f0, n, side);
-      HIP_TRY(hipEventRecord(join, side));
-      orbx::launch_octree(hp, dp, d_cand, d_cellCount, d_flatA, d_flatB, d_sel, d_selCount, d_octws, 0,
-                          hp.nlevels, f0, n, m);
-      orbx::launch_assemble(hp, dp, d_sel, d_selCount, lap0, lap1, d_kps, d_work, d_n, d_mono, f0, n, m);
-      HIP_TRY(hipStreamWaitEvent(m, join, 0));
-      orbx::launch_describe(hp, dp, d_pyr, d_blur, d_work, d_n, d_kps, d_desc, f0, n, m);
-      return ORBX_OK;
-    };
     if (nparts > 1) {
       HIP_TRY(hipEventRecord(evStart, s));            // the second stream follows earlier work on s
       HIP_TRY(hipStreamWaitEvent(lane[1], evStart, 0));
@@ -592,8 +690,8 @@ int orbx_extractor::run(const uint8_t* d_images, int istride, size_t iframe, int
       hipStream_t m = odd ? lane[1] : s;
       // a part starts its pyramid when the previous part's pyramid is done
       if (k > 0) HIP_TRY(hipStreamWaitEvent(m, evPyr[k - 1], 0));
-      const int st = part(k, m, odd ? lane[2] : lane[0], odd ? evForkB : evFork, odd ? evJoin[2] : evJoin[0],
-                          f0, n, k + 1 < nparts ? evPyr[k] : nullptr);
+      const int st = enqueuePart(k, m, odd ? lane[2] : lane[0], odd ? evForkB : evFork, odd ? evJoin[2] : evJoin[0],
+                                 f0, n, k + 1 < nparts ? evPyr[k] : nullptr, d_images, istride, iframe, lap0, lap1);
       if (st != ORBX_OK) return st;
       f0 += n;
     }
@@ -605,6 +703,34 @@ int orbx_extractor::run(const uint8_t* d_images, int istride, size_t iframe, int
   }
   evValid = prof;
   HIP_TRY(hipGetLastError());
+  afterExtraction(nframes);
+  return ORBX_OK;
+}
+
+// One part of a batch (frames [f0, f0 + n)) on main stream m with the blur on `side`: the blur
+// only needs the pyramid, so it runs beside the latency-bound quadtree.
+int orbx_extractor::enqueuePart(int pk, hipStream_t m, hipStream_t side, hipEvent_t fork, hipEvent_t join,
+                                int f0, int n, hipEvent_t pyrDone, const uint8_t* d_images, int istride,
+                                size_t iframe, int lap0, int lap1) {
+  orbx::launch_pyramid(hp, d_images, istride, iframe, d_pyr, f0, n, m);
+  if (pyrDone) HIP_TRY(hipEventRecord(pyrDone, m));
+  HIP_TRY(hipEventRecord(evDet[pk][0], m));
+  orbx::launch_fast(hp, dp, d_pyr, d_cand, d_cellCount, 0, hp.nlevels, f0, n, m);
+  HIP_TRY(hipEventRecord(evDet[pk][1], m));
+  detFrames[pk] = n;
+  HIP_TRY(hipEventRecord(fork, m));
+  HIP_TRY(hipStreamWaitEvent(side, fork, 0));
+  orbx::launch_blur(hp, dp, d_pyr, d_blur, f0, n, side);
+  HIP_TRY(hipEventRecord(join, side));
+  orbx::launch_octree(hp, dp, d_cand, d_cellCount, d_flatA, d_flatB, d_sel, d_selCount, d_octws, 0,
+                      hp.nlevels, f0, n, m);
+  orbx::launch_assemble(hp, dp, d_sel, d_selCount, lap0, lap1, d_kps, d_work, d_n, d_mono, f0, n, m);
+  HIP_TRY(hipStreamWaitEvent(m, join, 0));
+  orbx::launch_describe(hp, dp, d_pyr, d_blur, d_work, d_n, d_kps, d_desc, f0, n, m);
+  return ORBX_OK;
+}
+
+void orbx_extractor::afterExtraction(int nframes) {
   lastFrames = nframes;
   // results derived from the previous extraction (stereo association, frame grid, bag of words)
   // describe keypoints that no longer exist: their download / query calls fail until the
@@ -612,8 +738,7 @@ int orbx_extractor::run(const uint8_t* d_images, int istride, size_t iframe, int
   stereoFrames = 0;
   gridFrames = 0;
   bowFrames = 0;
-  std::fill(h_pyr_valid.begin(), h_pyr_valid.end(), 0);
-  return ORBX_OK;
+  h_pyr_valid = false;
 }
 
 // ---------------------------------------------------------------------------
@@ -672,6 +797,12 @@ int orbx_create(const orbx_params* p, orbx_extractor** out) {
   for (int k = 0; k < orbx_extractor::kLanes && ok; ++k)
     ok = hipStreamCreateWithFlags(&ex->lane[k], hipStreamNonBlocking) == hipSuccess &&
          hipEventCreateWithFlags(&ex->evJoin[k], hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipStreamCreateWithFlags(&ex->sIn, hipStreamNonBlocking) == hipSuccess &&
+       hipStreamCreateWithFlags(&ex->sOut, hipStreamNonBlocking) == hipSuccess;
+  for (int i = 0; i < 2 && ok; ++i)
+    ok = hipEventCreateWithFlags(&ex->evIn[i], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&ex->evComp[i], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&ex->evOut[i], hipEventDisableTiming) == hipSuccess;
   if (!ok) { orbx_destroy(ex); return ORBX_ERR_NO_DEVICE; }
   *out = ex;
   return ORBX_OK;
@@ -692,8 +823,15 @@ void orbx_destroy(orbx_extractor* ex) {
   for (int k = 0; k < orbx_extractor::kMaxParts; ++k) if (ex->evPyr[k]) (void)hipEventDestroy(ex->evPyr[k]);
   if (ex->evForkB) (void)hipEventDestroy(ex->evForkB);
   if (ex->evStereo) (void)hipEventDestroy(ex->evStereo);
-  for (int i = 0; i < 2; ++i) if (ex->evIn[i]) (void)hipEventDestroy(ex->evIn[i]);
+  for (int i = 0; i < 2; ++i) {
+    if (ex->evIn[i]) (void)hipEventDestroy(ex->evIn[i]);
+    if (ex->evComp[i]) (void)hipEventDestroy(ex->evComp[i]);
+    if (ex->evOut[i]) (void)hipEventDestroy(ex->evOut[i]);
+  }
+  if (ex->sIn) { (void)hipStreamSynchronize(ex->sIn); (void)hipStreamDestroy(ex->sIn); }
+  if (ex->sOut) { (void)hipStreamSynchronize(ex->sOut); (void)hipStreamDestroy(ex->sOut); }
   if (ex->stream) (void)hipStreamDestroy(ex->stream);
+  delete ex->pool;
   delete ex;
 }
 
@@ -780,63 +918,167 @@ int orbx_batch_download(orbx_extractor* ex, int frame, orbx_keypoint* kps, uint8
   return ORBX_OK;
 }
 
+namespace {
+// Is [p, p + bytes) page-locked host memory the GPU can reach directly (hipHostMalloc /
+// hipHostRegister)?  Ordinary (pageable) memory makes the query fail; that failure is expected
+// and must not stay behind as the thread's last HIP error.
+bool is_pinned_host(const void* p, size_t bytes) {
+  if (!p) return false;
+  hipPointerAttribute_t a;
+  const uint8_t* ends[2] = {(const uint8_t*)p, (const uint8_t*)p + (bytes ? bytes - 1 : 0)};
+  for (const uint8_t* q : ends) {
+    std::memset(&a, 0, sizeof(a));
+    if (hipPointerGetAttributes(&a, q) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (a.type != hipMemoryTypeHost) return false;
+  }
+  return true;
+}
+}  // namespace
+
 int orbx_extract_batch(orbx_extractor* ex, int n_frames, const uint8_t* const* imgs, int width,
                        int height, int stride, int lap0, int lap1, orbx_keypoint* kps,
                        uint8_t* desc, int cap, int* n_out, int* mono_out) {
   if (!ex) return ORBX_ERR_BAD_ARG;
   if (!imgs || width <= 0 || height <= 0 || n_frames <= 0) return ORBX_ERR_EMPTY_IMAGE;
   for (int f = 0; f < n_frames; ++f) if (!imgs[f]) return ORBX_ERR_EMPTY_IMAGE;
-  if (stride < width) return ORBX_ERR_BAD_ARG;
+  if (stride < width || cap < 0) return ORBX_ERR_BAD_ARG;
   if (n_frames > ex->prm.max_batch) return ORBX_ERR_BATCH;
   if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
   int st = ex->ensurePlan(width, height);
   if (st != ORBX_OK) { ex->freePlan(); return st; }
   auto& last_hip_error = ex->last_hip_error;
-  hipStream_t s = ex->stream;
   const size_t frameBytes = (size_t)width * height;
-  const int CH = ex->stageFrames;
-  // images: rows are packed into a pinned buffer by the CPU (a pageable 2-D copy would be
-  // split into one transfer per row), then one transfer per group of frames
-  for (int c0 = 0, k = 0; c0 < n_frames; c0 += CH, ++k) {
-    const int b = k & 1, c1 = std::min(c0 + CH, n_frames);
-    if (!ex->evIn[b]) HIP_TRY(hipEventCreateWithFlags(&ex->evIn[b], hipEventDisableTiming));
-    if (ex->evInUsed[b]) HIP_TRY(hipEventSynchronize(ex->evIn[b]));
-    for (int f = c0; f < c1; ++f) {
-      uint8_t* dst = ex->h_in[b] + (size_t)(f - c0) * frameBytes;
-      if (stride == width) std::memcpy(dst, imgs[f], frameBytes);
-      else for (int y = 0; y < height; ++y) std::memcpy(dst + (size_t)y * width, imgs[f] + (size_t)y * stride, width);
-    }
-    HIP_TRY(hipMemcpyAsync(ex->d_img + (size_t)c0 * frameBytes, ex->h_in[b], (size_t)(c1 - c0) * frameBytes,
-                           hipMemcpyHostToDevice, s));
-    HIP_TRY(hipEventRecord(ex->evIn[b], s));
-    ex->evInUsed[b] = true;
-  }
-  st = ex->run(ex->d_img, width, frameBytes, n_frames, lap0, lap1);
+  const size_t srcBytes = (size_t)stride * (height - 1) + width;
+  const int kc = ex->hp.kp_cap, G = ex->groupFrames;
+  const int ngroups = (n_frames + G - 1) / G;
+
+  // caller memory the copy engines can use directly needs no staging and no CPU copy
+  bool pinnedIn = true;
+  for (int f = 0; f < n_frames && pinnedIn; ++f) pinnedIn = is_pinned_host(imgs[f], srcBytes);
+  const int ccap = std::min(cap, kc);                      // slots per frame the caller can take
+  const bool wantK = kps && ccap > 0, wantD = desc && ccap > 0;
+  const bool pinnedOut = (!wantK || is_pinned_host(kps, (size_t)n_frames * cap * 28)) &&
+                         (!wantD || is_pinned_host(desc, (size_t)n_frames * cap * 32));
+  const bool stageOut = !pinnedOut && (wantK || wantD);
+  st = ex->ensureHostStaging(!pinnedIn, stageOut);
   if (st != ORBX_OK) return st;
-  // results: counts first, then whole groups of keypoint / descriptor slots through pinned memory
+  HostPool* pool = ex->pool;
+  auto par = [&](int n, const std::function<void(int)>& fn) {
+    if (pool) pool->parallel_for(n, fn); else for (int i = 0; i < n; ++i) fn(i);
+  };
+
+  // work enqueued earlier on the handle's stream (a previous device-resident call) comes first
+  HIP_TRY(hipEventRecord(ex->evStart, ex->stream));
+  HIP_TRY(hipStreamWaitEvent(ex->lane[1], ex->evStart, 0));
+  HIP_TRY(hipStreamWaitEvent(ex->sIn, ex->evStart, 0));
+
   int worst = ORBX_OK;
-  const int kc = ex->hp.kp_cap;
-  for (int c0 = 0; c0 < n_frames; c0 += CH) {
-    const int c1 = std::min(c0 + CH, n_frames), m = c1 - c0;
-    int* hn = (int*)ex->h_out;
-    int* hm = hn + CH;
-    uint8_t* hk = ex->h_out + (size_t)CH * 8;
-    uint8_t* hd = hk + (size_t)CH * kc * 28;
-    HIP_TRY(hipMemcpyAsync(hn, ex->d_n + c0, (size_t)m * 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(hm, ex->d_mono + c0, (size_t)m * 4, hipMemcpyDeviceToHost, s));
-    if (kps) HIP_TRY(hipMemcpyAsync(hk, ex->d_kps + (size_t)c0 * kc * 7, (size_t)m * kc * 28, hipMemcpyDeviceToHost, s));
-    if (desc) HIP_TRY(hipMemcpyAsync(hd, ex->d_desc + (size_t)c0 * kc * 32, (size_t)m * kc * 32, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    for (int f = c0; f < c1; ++f) {
-      const int n = hn[f - c0];
-      if (n_out) n_out[f] = n;
-      if (mono_out) mono_out[f] = hm[f - c0];
-      if (n > cap) { worst = ORBX_ERR_CAPACITY; continue; }
-      if (kps) std::memcpy(kps + (size_t)f * cap, hk + (size_t)(f - c0) * kc * 28, (size_t)n * 28);
-      if (desc) std::memcpy(desc + (size_t)f * cap * 32, hd + (size_t)(f - c0) * kc * 32, (size_t)n * 32);
+  // group k is done on the device and its results are where the caller wants them
+  auto finish = [&](int k) -> int {
+    const int b = k & 1, f0 = k * G, m = std::min(G, n_frames - f0);
+    HIP_TRY(hipEventSynchronize(ex->evOut[b]));
+    const int* hn = ex->h_cnt[b];
+    const int* hm = hn + G;
+    for (int i = 0; i < m; ++i) {
+      if (n_out) n_out[f0 + i] = hn[i];
+      if (mono_out) mono_out[f0 + i] = hm[i];
+      if (hn[i] > cap) worst = ORBX_ERR_CAPACITY;
     }
+    if (stageOut) {
+      const uint8_t* hk = ex->h_out[b];
+      const uint8_t* hd = hk + (size_t)G * kc * 28;
+      par(m, [&](int i) {
+        const int n = std::min(hn[i], ccap);
+        if (hn[i] > cap || n <= 0) return;
+        if (wantK) std::memcpy(kps + (size_t)(f0 + i) * cap, hk + (size_t)i * kc * 28, (size_t)n * 28);
+        if (wantD) std::memcpy(desc + (size_t)(f0 + i) * cap * 32, hd + (size_t)i * kc * 32, (size_t)n * 32);
+      });
+    }
+    return ORBX_OK;
+  };
+
+  for (int k = 0; k < ngroups; ++k) {
+    const int b = k & 1, f0 = k * G, m = std::min(G, n_frames - f0);
+    uint8_t* dimg = ex->d_img + (size_t)f0 * frameBytes;
+    // ---- images to the device (copy-in stream)
+    if (pinnedIn) {
+      for (int i = 0; i < m;) {
+        if (stride == width) {
+          int j = i + 1;    // frames that follow each other in memory travel as one transfer
+          while (j < m && imgs[f0 + j] == imgs[f0 + j - 1] + frameBytes) ++j;
+          HIP_TRY(hipMemcpyAsync(dimg + (size_t)i * frameBytes, imgs[f0 + i], (size_t)(j - i) * frameBytes,
+                                 hipMemcpyHostToDevice, ex->sIn));
+          i = j;
+        } else {
+          HIP_TRY(hipMemcpy2DAsync(dimg + (size_t)i * frameBytes, width, imgs[f0 + i], stride, width, height,
+                                   hipMemcpyHostToDevice, ex->sIn));
+          ++i;
+        }
+      }
+    } else {
+      if (k >= 2) HIP_TRY(hipEventSynchronize(ex->evIn[b]));   // the staging buffer's last transfer is done
+      uint8_t* hin = ex->h_in[b];
+      par(m, [&](int i) {
+        uint8_t* dst = hin + (size_t)i * frameBytes;
+        const uint8_t* src = imgs[f0 + i];
+        if (stride == width) std::memcpy(dst, src, frameBytes);
+        else for (int y = 0; y < height; ++y) std::memcpy(dst + (size_t)y * width, src + (size_t)y * stride, width);
+      });
+      HIP_TRY(hipMemcpyAsync(dimg, hin, (size_t)m * frameBytes, hipMemcpyHostToDevice, ex->sIn));
+    }
+    HIP_TRY(hipEventRecord(ex->evIn[b], ex->sIn));
+    // ---- kernels: groups alternate between the handle's two stream pairs, like the parts of a
+    // device-resident batch
+    const bool odd = k & 1;
+    hipStream_t ms = odd ? ex->lane[1] : ex->stream;
+    HIP_TRY(hipStreamWaitEvent(ms, ex->evIn[b], 0));
+    st = ex->enqueuePart(b, ms, odd ? ex->lane[2] : ex->lane[0], odd ? ex->evForkB : ex->evFork,
+                         odd ? ex->evJoin[2] : ex->evJoin[0], f0, m, nullptr, ex->d_img, width, frameBytes,
+                         lap0, lap1);
+    if (st != ORBX_OK) return st;
+    HIP_TRY(hipEventRecord(ex->evComp[b], ms));
+    // ---- results to the host (copy-out stream); the staging buffers of group k-2 were emptied
+    // by finish(k-2) before this point
+    HIP_TRY(hipStreamWaitEvent(ex->sOut, ex->evComp[b], 0));
+    HIP_TRY(hipMemcpyAsync(ex->h_cnt[b], ex->d_n + f0, (size_t)m * 4, hipMemcpyDeviceToHost, ex->sOut));
+    HIP_TRY(hipMemcpyAsync(ex->h_cnt[b] + G, ex->d_mono + f0, (size_t)m * 4, hipMemcpyDeviceToHost, ex->sOut));
+    if (stageOut) {
+      uint8_t* hk = ex->h_out[b];
+      uint8_t* hd = hk + (size_t)G * kc * 28;
+      if (wantK) HIP_TRY(hipMemcpyAsync(hk, ex->d_kps + (size_t)f0 * kc * 7, (size_t)m * kc * 28, hipMemcpyDeviceToHost, ex->sOut));
+      if (wantD) HIP_TRY(hipMemcpyAsync(hd, ex->d_desc + (size_t)f0 * kc * 32, (size_t)m * kc * 32, hipMemcpyDeviceToHost, ex->sOut));
+    } else {
+      // straight into the caller's arrays: the first min(cap, slots) entries of every frame;
+      // entries beyond a frame's n_out are unspecified
+      if (wantK) HIP_TRY(hipMemcpy2DAsync(kps + (size_t)f0 * cap, (size_t)cap * 28, ex->d_kps + (size_t)f0 * kc * 7,
+                                          (size_t)kc * 28, (size_t)ccap * 28, m, hipMemcpyDeviceToHost, ex->sOut));
+      if (wantD) HIP_TRY(hipMemcpy2DAsync(desc + (size_t)f0 * cap * 32, (size_t)cap * 32, ex->d_desc + (size_t)f0 * kc * 32,
+                                          (size_t)kc * 32, (size_t)ccap * 32, m, hipMemcpyDeviceToHost, ex->sOut));
+    }
+    HIP_TRY(hipEventRecord(ex->evOut[b], ex->sOut));
+    if (k >= 1) { st = finish(k - 1); if (st != ORBX_OK) return st; }
   }
+  st = finish(ngroups - 1);
+  if (st != ORBX_OK) return st;
+  // later work on the handle's stream follows everything this call ran on the other streams
+  HIP_TRY(hipEventRecord(ex->evJoin[1], ex->lane[1]));
+  HIP_TRY(hipStreamWaitEvent(ex->stream, ex->evJoin[1], 0));
+  ex->lastParts = 0;
+  ex->evValid = false;
+  HIP_TRY(hipGetLastError());
+  ex->afterExtraction(n_frames);
   return worst;
+}
+
+int orbx_host_alloc(size_t bytes, void** out) {
+  if (!out || bytes == 0) return ORBX_ERR_BAD_ARG;
+  *out = nullptr;
+  return hipHostMalloc(out, bytes, hipHostMallocDefault) == hipSuccess ? ORBX_OK : ORBX_ERR_HIP;
+}
+
+int orbx_host_free(void* p) {
+  if (!p) return ORBX_OK;
+  return hipHostFree(p) == hipSuccess ? ORBX_OK : ORBX_ERR_HIP;
 }
 
 int orbx_extract(orbx_extractor* ex, const uint8_t* img, int width, int height, int stride, int lap0,
@@ -1534,19 +1776,32 @@ int orbx_pyramid(orbx_extractor* ex, int level, const uint8_t** padded, int* wid
                  int* stride) {
   if (!ex || !ex->planned || !padded || level < 0 || level >= ex->hp.nlevels || ex->lastFrames < 1)
     return ORBX_ERR_BAD_ARG;
-  // host mirror of frame 0's pyramid: all levels back to back
+  if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  auto& last_hip_error = ex->last_hip_error;
+  // host mirror of frame 0's pyramid: all levels back to back in pinned memory, fetched together
+  // on the first request after an extraction (eight transfers, one wait)
   size_t total = 0, off = 0;
   for (int l = 0; l < ex->hp.nlevels; ++l) {
     if (l == level) off = total;
     total += ex->hp.lv[l].pyr_plane;
   }
-  if (ex->h_pyr.size() != total) ex->h_pyr.assign(total, 0);
-  if (!ex->h_pyr_valid[level]) {
-    int st = orbx_debug_level_padded(ex, 0, level, ex->h_pyr.data() + off);
-    if (st != ORBX_OK) return st;
-    ex->h_pyr_valid[level] = 1;
+  if (ex->h_pyr_bytes != total) {
+    if (ex->h_pyr) (void)hipHostFree(ex->h_pyr);
+    ex->h_pyr = nullptr; ex->h_pyr_bytes = 0; ex->h_pyr_valid = false;
+    HIP_TRY(hipHostMalloc((void**)&ex->h_pyr, total, hipHostMallocDefault));
+    ex->h_pyr_bytes = total;
   }
-  *padded = ex->h_pyr.data() + off;
+  if (!ex->h_pyr_valid) {
+    size_t o = 0;
+    for (int l = 0; l < ex->hp.nlevels; ++l) {
+      const LevelDesc& L = ex->hp.lv[l];
+      HIP_TRY(hipMemcpyAsync(ex->h_pyr + o, ex->d_pyr + L.pyr_off, L.pyr_plane, hipMemcpyDeviceToHost, ex->stream));
+      o += L.pyr_plane;
+    }
+    HIP_TRY(hipStreamSynchronize(ex->stream));
+    ex->h_pyr_valid = true;
+  }
+  *padded = ex->h_pyr + off;
   return orbx_level_dims(ex, level, width, height, stride);
 }
 

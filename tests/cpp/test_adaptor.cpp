@@ -43,11 +43,34 @@ int main() {
   for (int i = 0; i < n; ++i) CHECK(std::memcmp(cd.data() + (size_t)i * 32, dL.ptr(i), 32) == 0);
   CHECK(orbx_cv::DescriptorDistance(dL(cv::Rect(0, 0, 32, 1)), dL(cv::Rect(0, 0, 32, 1))) == 0);
 
-  // pyramid views: level 0 equals the input, level sizes follow the tables
-  exL.SyncImagePyramid();
+  // mvImagePyramid is usable right after operator(), with no further call, as unchanged
+  // Frame::ComputeStereoMatches needs it (core/src/Frame.cc:837, 921-941): level 0 equals the
+  // input, level sizes follow the tables, and every level - border included - equals the padded
+  // plane the C ABI dumps for the same image
+  CHECK(exL.mvImagePyramid.size() == 8);
   CHECK(exL.mvImagePyramid[0].rows == H && exL.mvImagePyramid[0].cols == W);
   for (int y = 0; y < H; y += 37) CHECK(std::memcmp(exL.mvImagePyramid[0].ptr(y), left.ptr(y), W) == 0);
   CHECK(exL.mvImagePyramid[1].cols == 627 && exL.mvImagePyramid[1].rows == 400);
+  for (int l = 0; l < 8; ++l) {
+    int lw = 0, lh = 0, ls = 0;
+    CHECK(orbx_level_dims(h, l, &lw, &lh, &ls) == ORBX_OK);
+    std::vector<uint8_t> plane((size_t)(lh + 38) * ls);
+    CHECK(orbx_debug_level_padded(h, 0, l, plane.data()) == ORBX_OK);
+    const cv::Mat& m = exL.mvImagePyramid[l];
+    CHECK(m.rows == lh && m.cols == lw);
+    for (int y = -19; y < lh + 19; ++y)   // the ROI view sits inside its padded plane
+      CHECK(std::memcmp(m.ptr(0) + (long)y * (long)m.step - 19, plane.data() + (size_t)(y + 19) * ls, lw + 38) == 0);
+  }
+  {
+    // a device-side stereo consumer opts out of the transfer: empty Mats until asked
+    orbx_cv::ORBextractor exD(1200, 1.2f, 8, 20, 7, 0, /*hostPyramid=*/false);
+    std::vector<cv::KeyPoint> kD;
+    cv::Mat dD;
+    CHECK(exD(left, cv::Mat(), kD, dD, lap) == monoL && kD.size() == kL.size());
+    CHECK(exD.mvImagePyramid[0].empty());
+    exD.SyncImagePyramid();
+    CHECK(exD.mvImagePyramid[0].rows == H && std::memcmp(exD.mvImagePyramid[0].ptr(5), left.ptr(5), W) == 0);
+  }
 
   // stereo association and 2-NN
   std::vector<float> uR, depth;

@@ -66,6 +66,8 @@ struct hostsim_event;
 typedef hostsim_stream* hipStream_t;
 typedef hostsim_event* hipEvent_t;
 enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0 };
+enum hipMemoryType { hipMemoryTypeUnregistered = 0, hipMemoryTypeHost = 1, hipMemoryTypeDevice = 2 };
+struct hipPointerAttribute_t { int type; int device; void* devicePointer; void* hostPointer; };
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 
 // a file-scope __device__ array is an ordinary host array here: its "device address" is its own
@@ -82,6 +84,7 @@ hipError_t hipMallocAsync(void** p, size_t n, hipStream_t s);
 hipError_t hipFreeAsync(void* p, hipStream_t s);
 hipError_t hipHostMalloc(void** p, size_t n, unsigned flags);
 hipError_t hipHostFree(void* p);
+hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* p);
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind k);
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t st);
 hipError_t hipMemcpy2D(void* d, size_t dpitch, const void* s, size_t spitch, size_t w, size_t h, hipMemcpyKind k);

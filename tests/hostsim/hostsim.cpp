@@ -623,8 +623,34 @@ hipError_t hipFree(void* p) {
 }
 hipError_t hipMallocAsync(void** p, size_t n, hipStream_t) { return hipMalloc(p, n); }
 hipError_t hipFreeAsync(void* p, hipStream_t) { return hipFree(p); }
-hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
-hipError_t hipHostFree(void* p) { return hipFree(p); }
+// page-locked host allocations are remembered so that hipPointerGetAttributes can tell them
+// from ordinary host memory, as the runtime does
+static std::mutex g_pinned_mu;
+static std::map<uintptr_t, size_t> g_pinned;
+hipError_t hipHostMalloc(void** p, size_t n, unsigned) {
+  const hipError_t e = hipMalloc(p, n);
+  if (e == hipSuccess) {
+    std::lock_guard<std::mutex> lk(g_pinned_mu);
+    g_pinned[(uintptr_t)*p] = n;
+  }
+  return e;
+}
+hipError_t hipHostFree(void* p) {
+  {
+    std::lock_guard<std::mutex> lk(g_pinned_mu);
+    g_pinned.erase((uintptr_t)p);
+  }
+  return hipFree(p);
+}
+hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* p) {
+  std::lock_guard<std::mutex> lk(g_pinned_mu);
+  auto it = g_pinned.upper_bound((uintptr_t)p);
+  if (it != g_pinned.begin()) {
+    --it;
+    if ((uintptr_t)p < it->first + it->second) { a->type = hipMemoryTypeHost; return hipSuccess; }
+  }
+  return hipErrorInvalidValue;
+}
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) {
   if (getenv("HOSTSIM_TRACE")) fprintf(stderr, "hostsim: memcpy %p <- %p, %zu bytes\n", d, s, n);
   if (n) memmove(d, s, n);

@@ -76,3 +76,21 @@ def test_sharded_knn_equals_unsharded(oracle, world):
         assert p.exitcode == 0
     for r in range(world):
         assert np.array_equal(out[r][0], ridx) and np.array_equal(out[r][1], rdist)
+
+
+def test_bench_spawns_ranks_itself():
+    """`python bench.py --gpus 2` outside a launcher starts two ranks with torch.distributed.run
+    (before it touches torch or HIP), they meet over gloo, and rank 0's JSON line reports both.
+    --dry-run-cpu stops short of the hot path, which needs a GPU."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-cpu",
+                        "--steps", "3", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["dry_run"] is True and j["steps"] == 3
+    assert abs(j["max_over_ranks_s"] - 0.002) < 1e-9           # rank 1's figure won the reduction
+    assert j["shard_bounds"] == [0, 5_000_000, 10_000_000]

@@ -212,3 +212,69 @@ def test_split_batch_matches_single_frames():
         mono, k, d = res[f]
         rmono, rk, rd = ref[f % 5]
         assert mono == rmono and np.array_equal(k, rk) and np.array_equal(d, rd), f
+
+
+def _pinned_array(shape, dtype):
+    """numpy array over page-locked host memory from the library (orbx_host_alloc)."""
+    import ctypes as C
+    from orb_slam3_amd._lib import lib, check
+    nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    p = C.c_void_p()
+    check(lib().orbx_host_alloc(nbytes, C.byref(p)), "orbx_host_alloc")
+    buf = (C.c_uint8 * nbytes).from_address(p.value)
+    return np.frombuffer(buf, dtype).reshape(shape), p
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_host_batch_pipeline_groups(oracle, pinned, monkeypatch):
+    """orbx_extract_batch over several groups of frames (transfers and kernels of neighbouring
+    groups overlap; group size forced small so that 11 frames make 4 groups, the last one short):
+    pageable caller memory (staged by host threads) and page-locked caller memory (copied
+    directly), contiguous and strided rows - every frame equals the oracle."""
+    import ctypes as C
+    from orb_slam3_amd._lib import lib, check, KEYPOINT_DTYPE
+    monkeypatch.setenv("ORBX_HOST_GROUP", "3")
+    W, H, B, stride = 376, 240, 11, 384
+    frames = [orbx.textured_frame(900 + i, W, H) for i in range(B)]
+    ex = orbx.ORBextractor(400, 1.2, 6, 20, 7, max_batch=B)
+    cap = ex.max_keypoints()
+    holds = []
+    if pinned:
+        imgs, h0 = _pinned_array((B, H, stride), np.uint8)
+        kps, h1 = _pinned_array((B, cap), KEYPOINT_DTYPE)
+        desc, h2 = _pinned_array((B, cap, 32), np.uint8)
+        holds = [h0, h1, h2]
+    else:
+        imgs = np.zeros((B, H, stride), np.uint8)
+        kps = np.zeros((B, cap), KEYPOINT_DTYPE)
+        desc = np.zeros((B, cap, 32), np.uint8)
+    imgs[:] = 0x5A
+    for f in range(B):
+        imgs[f, :, :W] = frames[f]
+    n = np.zeros(B, np.int32)
+    mono = np.zeros(B, np.int32)
+    i32p = C.POINTER(C.c_int32)
+    for use_stride in (stride, W):
+        if use_stride == W:
+            src = imgs.reshape(-1)[:B * H * W].reshape(B, H, W)     # same memory, rows packed
+            for f in range(B):
+                src[f] = frames[f]
+        else:
+            src = imgs
+        ptrs = (C.c_void_p * B)(*[src[i].ctypes.data for i in range(B)])
+        kps[:] = np.zeros((), KEYPOINT_DTYPE)
+        desc[:] = 0
+        check(lib().orbx_extract_batch(ex._h, B, ptrs, W, H, use_stride, 0, 1000, kps.ctypes.data_as(C.c_void_p),
+                                       desc.ctypes.data_as(C.c_void_p), cap, n.ctypes.data_as(i32p),
+                                       mono.ctypes.data_as(i32p)), "orbx_extract_batch")
+        for f in range(B):
+            st, rmono, rk, rd = oracle.Extractor(400, 1.2, 6, 20, 7).extract(frames[f], (0, 1000))
+            assert st == 0 and n[f] == len(rk) and mono[f] == rmono, (f, use_stride)
+            k = kps[f, :n[f]]
+            for fld in ("x", "y", "size", "response", "octave", "class_id"):
+                assert np.array_equal(k[fld], rk[fld]), (f, fld)
+            assert np.array_equal(desc[f, :n[f]], rd), f
+    ex.close()
+    from orb_slam3_amd._lib import lib as _l
+    for h in holds:
+        _l().orbx_host_free(h)

@@ -10,7 +10,7 @@ mkdir -p "$OUT"
 cd "$R"
 run() {   # name, then VAR=value pairs
   local name=$1; shift
-  env "$@" timeout -k 10 240 python bench.py --no-cpu --no-match --stage-times --steps 20 --warmup 3 > "$OUT/$name.log" 2>&1
+  env "$@" timeout -k 10 240 python bench.py --no-cpu --no-match --no-extra --stage-times --steps 20 --warmup 3 > "$OUT/$name.log" 2>&1
   python - "$OUT/$name.log" "$name" <<'PY'
 import json, sys
 line = [l for l in open(sys.argv[1]) if l.startswith("{")][-1]
@@ -24,7 +24,7 @@ run single_pass ORBX_FAST_SINGLE_PASS=1
 for k in 2048 4096 8192; do run oct_keys_lds_$k ORBX_OCT_KEYS_LDS=$k; done
 # the guided matchers with and without a chip-wide launch for the window walks
 for g in 0 1; do
-  ORBX_GUIDED_GATHER=$g timeout -k 10 240 python bench.py --no-cpu --no-match --guided --steps 5 --warmup 2 > "$OUT/guided_gather_$g.log" 2>&1
+  ORBX_GUIDED_GATHER=$g timeout -k 10 240 python bench.py --no-cpu --no-match --no-extra --guided --steps 5 --warmup 2 > "$OUT/guided_gather_$g.log" 2>&1
   python - "$OUT/guided_gather_$g.log" "$g" <<'PY'
 import json, sys
 j = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])["guided"]

@@ -59,9 +59,16 @@ def main():
             # 4 SIMDs per CU each issue VALU independently; ACTIVE_INST_VALU is in quad-cycles
             r["valu_per_wave"] = r["SQ_INSTS_VALU"] / max(r.get("SQ_WAVES", 1), 1)
         res[k] = r
+    # the code state the counters belong to: bench.py only quotes a summary whose state matches
+    # the configuration it is running
+    res["_meta"] = {"fast_two_pass": 0 if os.environ.get("ORBX_FAST_SINGLE_PASS") == "1" else 1,
+                    "command": "python3 bench.py --steps 2 --warmup 1 --no-cpu --no-match --no-extra "
+                               "(one rocprofv3 --pmc pass per counter group)"}
     with open(os.path.join(out, "%s_pmc_summary.json" % tag), "w") as fh:
         json.dump(res, fh, indent=1, sort_keys=True)
     for k, r in res.items():
+        if k.startswith("_"):
+            continue
         print(k, {a: (round(b, 1) if isinstance(b, float) else b) for a, b in r.items()})
 
 
