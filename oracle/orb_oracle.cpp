@@ -1440,7 +1440,11 @@ void* orc_voc_load_text(const char* path) {
   v->nodes.resize(1);
   for (;;) {
     int pid, leaf;
-    if (std::fscanf(f, "%d %d", &pid, &leaf) != 2) break;
+    const int got = std::fscanf(f, "%d %d", &pid, &leaf);
+    if (got != 2) {   // only the end of the file ends the node list; a damaged line fails the load
+      if (!(got == EOF && std::feof(f))) { std::fclose(f); delete v; return nullptr; }
+      break;
+    }
     uint8_t d[32];
     bool ok = true;
     for (int i = 0; i < 32 && ok; ++i) {

@@ -318,7 +318,13 @@ int orbx_vocabulary_load_text(const char* path, int device_id, orbx_vocabulary**
   bool ok = true;
   for (;;) {
     int pid, isLeaf;
-    if (std::fscanf(f, "%d %d", &pid, &isLeaf) != 2) break;   // end of file / a line without a node
+    const int got = std::fscanf(f, "%d %d", &pid, &isLeaf);
+    if (got != 2) {
+      // only the end of the file (after optional white space, such as a trailing newline) ends the
+      // list; anything else that is not a node is a damaged file, not a shorter vocabulary
+      ok = got == EOF && std::feof(f);
+      break;
+    }
     for (int i = 0; i < 32 && ok; ++i) {
       int b;
       ok = std::fscanf(f, "%d", &b) == 1;

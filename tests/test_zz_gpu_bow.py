@@ -94,6 +94,18 @@ def test_bow_argument_errors(tmp_path):
     assert e.value.status == ORBX_ERR_BAD_ARG
     with pytest.raises(OrbxError):
         bow.ORBVocabulary(tmp_path / "missing.txt")
+    # a damaged line in the middle of a text file fails the load (it is not taken for the end of
+    # a shorter vocabulary); a file with or without a trailing newline loads all its nodes
+    good = tmp_path / "good.txt"
+    for nl in (True, False):
+        voc_util.write_text(good, 4, 2, arrays, trailing_newline=nl)
+        assert bow.ORBVocabulary(good).info()[2] == len(arrays[0]) + 1
+    lines = good.read_text().split("\n")
+    lines[len(lines) // 2] = "3 x" + lines[len(lines) // 2][3:]
+    (tmp_path / "damaged.txt").write_text("\n".join(lines))
+    with pytest.raises(OrbxError) as e:
+        bow.ORBVocabulary(tmp_path / "damaged.txt")
+    assert e.value.status == ORBX_ERR_BAD_ARG
     voc = bow.ORBVocabulary.from_arrays(4, 2, *arrays)
     ex = orbx.ORBextractor(300, 1.2, 4, 20, 7)
     ex(orbx.textured_frame(1, 376, 240), None, (0, 0))
