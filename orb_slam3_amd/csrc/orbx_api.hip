@@ -150,8 +150,12 @@ class HostPool {
     }
     cv_.notify_all();
     work();
+    // A job is over when every item is done AND no thread is still inside work() with this job's
+    // function: a worker that woke late must not claim an index of the next job with this one's
+    // (by then destroyed) function.  Threads enter work() only under the lock and only while
+    // fn_ is set, so nothing can start between here and the next job.
     std::unique_lock<std::mutex> lk(mu_);
-    idle_.wait(lk, [this] { return done_ == n_; });
+    idle_.wait(lk, [this] { return done_ == n_ && active_ == 0; });
     fn_ = nullptr;
   }
 
@@ -162,20 +166,20 @@ class HostPool {
     int n;
     {
       std::lock_guard<std::mutex> lk(mu_);
+      if (!fn_) return;
       fn = fn_; n = n_;
+      ++active_;
     }
-    if (!fn) return;
     for (;;) {
       const int i = next_.fetch_add(1);
       if (i >= n) break;
       (*fn)(i);
       ++mine;
     }
-    if (mine) {
-      std::lock_guard<std::mutex> lk(mu_);
-      done_ += mine;
-      if (done_ == n_) idle_.notify_all();
-    }
+    std::lock_guard<std::mutex> lk(mu_);
+    done_ += mine;
+    --active_;
+    if (done_ == n_ && active_ == 0) idle_.notify_all();
   }
   void loop() {
     unsigned seen = 0;
@@ -193,7 +197,7 @@ class HostPool {
   std::mutex mu_;
   std::condition_variable cv_, idle_;
   const std::function<void(int)>* fn_ = nullptr;
-  int n_ = 0, done_ = 0;
+  int n_ = 0, done_ = 0, active_ = 0;
   std::atomic<int> next_{0};
   unsigned epoch_ = 0;
   bool stop_ = false;

@@ -341,129 +341,236 @@ __device__ __forceinline__ int fast_m(const uint8_t* c) {
   return max(max(best_dark, -best_bright), 0);
 }
 
-typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
-typedef short ss2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
-  return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us2_t, a), __builtin_bit_cast(us2_t, b)));
-}
-__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
-  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2_t, a), __builtin_bit_cast(us2_t, b)));
-}
-__device__ __forceinline__ uint32_t pk_add_u16(uint32_t a, uint32_t b) {
-  return __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2_t, a) + __builtin_bit_cast(us2_t, b));
-}
-__device__ __forceinline__ uint32_t pk_sub_i16(uint32_t a, uint32_t b) {
-  return __builtin_bit_cast(uint32_t, __builtin_bit_cast(ss2_t, a) - __builtin_bit_cast(ss2_t, b));
-}
-__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
-  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(ss2_t, a), __builtin_bit_cast(ss2_t, b)));
+// The largest m' such that nine contiguous ring pixels are all darker than the centre by more
+// than m' - 1 (DARK) or all brighter (BRIGHT): the one-sided half of fast_m.  A pixel cannot be a
+// dark and a bright corner at once, so where the quick test has excluded one side the other side
+// alone is the pixel's m whenever that m exceeds the threshold.
+template <int TS, bool BRIGHT>
+__device__ __forceinline__ int fast_m_side(const uint8_t* c) {
+  const int v = c[0];
+  int d[16];
+  d[0] = c[3 * TS + 0];
+  d[1] = c[3 * TS + 1];
+  d[2] = c[2 * TS + 2];
+  d[3] = c[1 * TS + 3];
+  d[4] = c[3];
+  d[5] = c[-1 * TS + 3];
+  d[6] = c[-2 * TS + 2];
+  d[7] = c[-3 * TS + 1];
+  d[8] = c[-3 * TS + 0];
+  d[9] = c[-3 * TS - 1];
+  d[10] = c[-2 * TS - 2];
+  d[11] = c[-1 * TS - 3];
+  d[12] = c[-3];
+  d[13] = c[1 * TS - 3];
+  d[14] = c[2 * TS - 2];
+  d[15] = c[3 * TS - 1];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) d[k] = BRIGHT ? d[k] - v : v - d[k];
+  int lo2[16], lo4[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) lo2[k] = min(d[k], d[(k + 1) & 15]);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) lo4[k] = min(lo2[k], lo2[(k + 2) & 15]);
+  int best = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k)   // window of 9 starting at k: [k,k+4) u [k+4,k+8) u {k+8}
+    best = max(best, min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]));
+  return best;
 }
 
-// Bytes B0 and B0+2 of a 12-byte window row (three dwords) as two 16-bit lanes.
-template <int B0>
-__device__ __forceinline__ uint32_t pick2(const uint32_t (&row)[3]) {
-  static_assert(B0 >= 0 && B0 + 2 < 12, "byte index");
-  if (B0 + 2 <= 7) {
-    return __builtin_amdgcn_perm(row[1], row[0], 0x0c000c00u | (uint32_t)B0 | ((uint32_t)(B0 + 2) << 16));
-  } else {
-    return __builtin_amdgcn_perm(row[2], row[1], 0x0c000c00u | (uint32_t)(B0 - 4) | ((uint32_t)(B0 - 2) << 16));
+// The same with the side chosen per lane (sign = 0: bright, -1: dark): (I ^ s) - (v ^ s) is
+// I - v or v - I.  Seventeen more instructions than a one-sided loop, which pays when dark and
+// bright candidates together fill one trip of the wave.
+template <int TS>
+__device__ __forceinline__ int fast_m_signed(const uint8_t* c, int s) {
+  const int v = (int)c[0] ^ s;
+  int d[16];
+  d[0] = c[3 * TS + 0];
+  d[1] = c[3 * TS + 1];
+  d[2] = c[2 * TS + 2];
+  d[3] = c[1 * TS + 3];
+  d[4] = c[3];
+  d[5] = c[-1 * TS + 3];
+  d[6] = c[-2 * TS + 2];
+  d[7] = c[-3 * TS + 1];
+  d[8] = c[-3 * TS + 0];
+  d[9] = c[-3 * TS - 1];
+  d[10] = c[-2 * TS - 2];
+  d[11] = c[-1 * TS - 3];
+  d[12] = c[-3];
+  d[13] = c[1 * TS - 3];
+  d[14] = c[2 * TS - 2];
+  d[15] = c[3 * TS - 1];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) d[k] = (d[k] ^ s) - v;
+  int lo2[16], lo4[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) lo2[k] = min(d[k], d[(k + 1) & 15]);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) lo4[k] = min(lo2[k], lo2[(k + 2) & 15]);
+  int best = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k)
+    best = max(best, min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]));
+  return best;
+}
+
+// Quick corner test for the four pixels at window bytes 4..7 of window row WR, four pixels per
+// instruction on halved pixel values (7 bits in a byte, bit 7 free to catch the carry of a
+// per-byte comparison).  R = 8 window rows x 3 dwords of the halved tile.
+//
+// With I7 = I >> 1, v7 = v >> 1 and c = (t + 1) >> 1: a ring pixel darker than the centre by more
+// than t has I7 <= v7 - c, a brighter one I7 >= v7 + c (necessary, not sufficient: the halving
+// loosens both by at most one grey level).  A 9-arc holds one pixel of each of the 8 opposite
+// ring pairs, so a dark (bright) corner needs a dark (bright) pixel in every pair; the 4 axis and
+// diagonal pairs are tested.  Per byte, with nt = min(0x7f - v7 + c, 0x80) and
+// ug = 0x80 | min(v7 + c - 1, 0x7f):
+//   bit 7 of (I7 + nt) = "not dark",   bit 7 of (ug - I7) = "not bright",
+// and neither operation carries or borrows across bytes.  kD = 0x7f7f7f7f + c * 0x01010101,
+// kU = (c - 1) * 0x01010101, 1 <= c <= 0x80.  Returns in bit 7 of each byte of dark / bright
+// whether the pixel can still be a dark / bright corner.
+template <int WR>
+__device__ __forceinline__ void quick4(const uint32_t (&R)[8][3], uint32_t kD, uint32_t kU, uint32_t& dark,
+                                       uint32_t& bright) {
+  const uint32_t V = R[WR][1];
+  uint32_t nt = kD - V;
+  const uint32_t h = nt & 0x80808080u;
+  nt &= ~(h - (h >> 7));
+  const uint32_t s = V + kU;
+  const uint32_t g = s & 0x80808080u;
+  const uint32_t ug = s | (g - (g >> 7)) | 0x80808080u;
+  uint32_t nd, nb;
+  {   // (0,3) / (0,-3): aligned
+    const uint32_t a = R[WR + 3][1], b = R[WR - 3][1];
+    nd = (a + nt) & (b + nt);
+    nb = (ug - a) & (ug - b);
   }
-}
-
-// Quick corner test for the two pixels at window bytes C and C+2 of window
-// row WR (R = 8 window rows x 3 dwords).  Returns a packed pair of signed
-// 16-bit values, positive where the pixel may be a corner at threshold t.
-template <int WR, int C>
-__device__ __forceinline__ uint32_t quick_pair(const uint32_t (&R)[8][3], uint32_t tt) {
-  const uint32_t v = pick2<C>(R[WR]);
-  // four of the eight opposite ring pairs (dx,dy) / (-dx,-dy): the axes and the diagonals.
-  // Any subset of the pairs is a valid necessary condition; on edge-like structure these
-  // four reject almost as much as all eight at half the cost.
-  const uint32_t a0 = pick2<C + 0>(R[WR + 3]), b0 = pick2<C + 0>(R[WR - 3]);
-  const uint32_t a2 = pick2<C + 2>(R[WR + 2]), b2 = pick2<C - 2>(R[WR - 2]);
-  const uint32_t a4 = pick2<C + 3>(R[WR]),     b4 = pick2<C - 3>(R[WR]);
-  const uint32_t a6 = pick2<C + 2>(R[WR - 2]), b6 = pick2<C - 2>(R[WR + 2]);
-  uint32_t lo = pk_min_u16(a0, b0), hi = pk_max_u16(a0, b0);
-  lo = pk_max_u16(lo, pk_min_u16(a2, b2)); hi = pk_min_u16(hi, pk_max_u16(a2, b2));
-  lo = pk_max_u16(lo, pk_min_u16(a4, b4)); hi = pk_min_u16(hi, pk_max_u16(a4, b4));
-  lo = pk_max_u16(lo, pk_min_u16(a6, b6)); hi = pk_min_u16(hi, pk_max_u16(a6, b6));
-  // dark arc possible: lo + t < v ; bright arc possible: hi > v + t
-  const uint32_t s1 = pk_sub_i16(v, pk_add_u16(lo, tt));
-  const uint32_t s2 = pk_sub_i16(hi, pk_add_u16(v, tt));
-  return pk_max_i16(s1, s2);
+  {   // (3,0) / (-3,0): bytes 7..10 and 1..4 of the centre row
+    const uint32_t a = __builtin_amdgcn_alignbyte(R[WR][2], R[WR][1], 3), b = __builtin_amdgcn_alignbyte(R[WR][1], R[WR][0], 1);
+    nd |= (a + nt) & (b + nt);
+    nb |= (ug - a) & (ug - b);
+  }
+  {   // (2,2) / (-2,-2)
+    const uint32_t a = __builtin_amdgcn_alignbyte(R[WR + 2][2], R[WR + 2][1], 2), b = __builtin_amdgcn_alignbyte(R[WR - 2][1], R[WR - 2][0], 2);
+    nd |= (a + nt) & (b + nt);
+    nb |= (ug - a) & (ug - b);
+  }
+  {   // (2,-2) / (-2,2)
+    const uint32_t a = __builtin_amdgcn_alignbyte(R[WR - 2][2], R[WR - 2][1], 2), b = __builtin_amdgcn_alignbyte(R[WR + 2][1], R[WR + 2][0], 2);
+    nd |= (a + nt) & (b + nt);
+    nb |= (ug - a) & (ug - b);
+  }
+  dark = ~nd & 0x80808080u;
+  bright = ~nb & 0x80808080u;
 }
 
 // One detection pass of a cell at threshold tlow (steps 2-4 of the kernel below): quick
 // rejection, exact m for the survivors, suppression.  bitsHi collects the suppressed corners
 // with m > thHi, bitsLo (may be null) those with m > thLo.  Returns whether any lane set a
-// bitsHi bit (workgroup-wide).
+// bitsHi bit (workgroup-wide).  half = the tile with every pixel halved; qcnt = two counters.
 template <int TS>
-__device__ __forceinline__ bool fast_pass(const uint8_t* tile, uint8_t* mm, uint16_t* queue, int qcap, int cw,
-                                          int ch, int lane, int tlow, int thHi, uint32_t* bitsHi, int thLo,
-                                          uint32_t* bitsLo) {
+__device__ __forceinline__ bool fast_pass(const uint8_t* tile, const uint8_t* half, uint8_t* mm, uint16_t* queue,
+                                          int* qcnt, int qcap, int cw, int ch, int lane, int tlow, int thHi,
+                                          uint32_t* bitsHi, int thLo, uint32_t* bitsLo) {
   const int np = cw * ch;
   const int ngx = (cw + 3) >> 2, nry = (ch + 1) >> 1;
   const int ntask = ngx * nry;
   const float rngx = 1.0f / (float)ngx;
   const float rcw = 1.0f / (float)cw;
-  const uint32_t tt = (uint32_t)tlow * 0x00010001u;
+  if (lane == 0) { qcnt[0] = 0; qcnt[1] = 0; }
+  __syncthreads();
   // ---- 2. quick rejection, 4 columns x 2 rows per lane ----------------------
-  int qn = 0;
-  for (int base = 0; base < ntask; base += 64) {
-    const int tsk = base + lane;
-    uint32_t flags = 0;
-    int x = 0, y = 0;
-    if (tsk < ntask) {
-      const int r = (int)(((float)tsk + 0.5f) * rngx);
-      x = (tsk - r * ngx) * 4;
-      y = r * 2;
-      uint32_t R[8][3];
-      const uint8_t* wp = tile + y * TS + x;
+  // Survivors that can be dark corners are queued from the front of the queue, those that can be
+  // bright corners from its back (a pixel that can be either goes to both); the position comes
+  // from an LDS counter, so the order inside a queue is arbitrary - nothing below depends on it.
+  if (tlow >= 1) {
+    const uint32_t c = (uint32_t)(tlow + 1) >> 1;
+    const uint32_t kD = 0x7f7f7f7fu + c * 0x01010101u, kU = (c - 1u) * 0x01010101u;
+    for (int base = 0; base < ntask; base += 64) {
+      const int tsk = base + lane;
+      if (tsk < ntask) {
+        const int r = (int)(((float)tsk + 0.5f) * rngx);
+        const int x = (tsk - r * ngx) * 4, y = r * 2;
+        uint32_t R[8][3];
+        const uint8_t* wp = half + y * TS + x;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const uint32_t* rp = (const uint32_t*)(wp + i * TS);
-        R[i][0] = rp[0]; R[i][1] = rp[1]; R[i][2] = rp[2];
+        for (int i = 0; i < 8; ++i) {
+          const uint32_t* rp = (const uint32_t*)(wp + i * TS);
+          R[i][0] = rp[0]; R[i][1] = rp[1]; R[i][2] = rp[2];
+        }
+        uint32_t d0, b0, d1, b1;
+        quick4<3>(R, kD, kU, d0, b0);   // row y
+        quick4<4>(R, kD, kU, d1, b1);   // row y + 1
+        // dark flags in bits 0, 8, 16, 24 (row y) and 4, 12, 20, 28 (row y + 1), bright flags one
+        // bit above them.  Pixels of the last column group / row that lie outside the cell are
+        // not masked here: the consumers of the queue skip them.
+        uint32_t F = (d0 >> 7) | (d1 >> 3) | (b0 >> 6) | (b1 >> 2);
+        if (F) {
+          const uint32_t pos0 = (uint32_t)((y << 7) | x);
+          const unsigned long long nn = (unsigned long long)__popc(F & 0x11111111u) |
+                                        ((unsigned long long)__popc(F & 0x22222222u) << 32);
+          const unsigned long long old = atomicAdd((unsigned long long*)qcnt, nn);
+          int qd = (int)(uint32_t)old, qb = qcap - 1 - (int)(uint32_t)(old >> 32);
+          while (F) {
+            const int bit = __ffs(F) - 1;
+            F &= F - 1;
+            const int isB = bit & 1;
+            const int at = isB ? qb : qd;
+            if ((unsigned)at < (unsigned)qcap) queue[at] = (uint16_t)(pos0 + (bit >> 3) + ((bit & 4) << 5));
+            qd += 1 - isB;
+            qb -= isB;
+          }
+        }
       }
-      const uint32_t e0 = quick_pair<3, 4>(R, tt);  // row y,   columns x, x+2
-      const uint32_t o0 = quick_pair<3, 5>(R, tt);  // row y,   columns x+1, x+3
-      const uint32_t e1 = quick_pair<4, 4>(R, tt);  // row y+1
-      const uint32_t o1 = quick_pair<4, 5>(R, tt);
-      flags |= ((int)(short)(e0 & 0xFFFF) > 0) ? 1u : 0u;
-      flags |= ((int)(short)(o0 & 0xFFFF) > 0) ? 2u : 0u;
-      flags |= ((int)e0 >> 16 > 0) ? 4u : 0u;
-      flags |= ((int)o0 >> 16 > 0) ? 8u : 0u;
-      flags |= ((int)(short)(e1 & 0xFFFF) > 0) ? 16u : 0u;
-      flags |= ((int)(short)(o1 & 0xFFFF) > 0) ? 32u : 0u;
-      flags |= ((int)e1 >> 16 > 0) ? 64u : 0u;
-      flags |= ((int)o1 >> 16 > 0) ? 128u : 0u;
-      // pixels outside the cell
-      uint32_t colmask = (x + 4 <= cw) ? 0xFu : ((1u << (cw - x)) - 1u);
-      uint32_t valid = colmask | ((y + 1 < ch) ? (colmask << 4) : 0u);
-      flags &= valid;
     }
-    const int c = __popc(flags);
-    const int inc = wave_incl_scan(c);
-    int qpos = qn + inc - c;
-    while (flags) {
-      const int b = __ffs(flags) - 1;
-      flags &= flags - 1;
-      if (qpos < qcap) queue[qpos] = (uint16_t)(((y + (b >> 2)) << 7) | (x + (b & 3)));
-      ++qpos;
-    }
-    qn += __shfl(inc, 63, 64);
+  }
+  __syncthreads();
+  // the map of m shares its LDS with the halved tile, which the quick test is done with
+  {
+    const int mmq = ((ch + 2) * TS + 15) >> 4;
+    for (int i = lane; i < mmq; i += 64) ((uint4*)mm)[i] = make_uint4(0, 0, 0, 0);
   }
   __syncthreads();
 
   // ---- 3. exact m for the survivors -----------------------------------------
   // (a cell with more survivors than the queue holds - noise-like content - is scored
-  // and suppressed pixel by pixel instead)
-  const bool overflow = qn > qcap;
-  const int nwork = overflow ? np : qn;
-  for (int qi = lane; qi < nwork; qi += 64) {
-    int x, y;
-    if (overflow) { y = (int)(((float)qi + 0.5f) * rcw); x = qi - y * cw; }
-    else { const int id = queue[qi]; x = id & 127; y = id >> 7; }
-    mm[(y + 1) * TS + x + 4] = (uint8_t)fast_m<TS>(tile + (y + 3) * TS + x + 4);
+  // and suppressed pixel by pixel instead; so is a pass at threshold 0)
+  const int nD = qcnt[0], nB = qcnt[1];
+  const bool overflow = tlow < 1 || nD + nB > qcap;
+  const int nwork = overflow ? np : nD + nB;
+  if (overflow) {
+    for (int qi = lane; qi < np; qi += 64) {
+      const int y = (int)(((float)qi + 0.5f) * rcw), x = qi - y * cw;
+      mm[(y + 1) * TS + x + 4] = (uint8_t)fast_m<TS>(tile + (y + 3) * TS + x + 4);
+    }
+  } else if (nwork <= 64) {
+    // one trip for both sides; a pixel queued on both sides is written by its dark entry first
+    // and maximised by its bright entry (LDS operations of one wave complete in order)
+    const bool have = lane < nwork, isB = lane >= nD;
+    const int id = have ? queue[isB ? qcap - 1 - (lane - nD) : lane] : 0;
+    const int x = id & 127, y = id >> 7;
+    const bool inside = have && x < cw && y < ch;
+    int m = 0;
+    if (inside) m = fast_m_signed<TS>(tile + (y + 3) * TS + x + 4, isB ? 0 : -1);
+    uint8_t* q = mm + (y + 1) * TS + x + 4;
+    if (inside && !isB) *q = (uint8_t)m;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (inside && isB) *q = (uint8_t)max((int)*q, m);
+  } else {
+    for (int qi = lane; qi < nD; qi += 64) {
+      const int id = queue[qi], x = id & 127, y = id >> 7;
+      if (x < cw && y < ch) mm[(y + 1) * TS + x + 4] = (uint8_t)fast_m_side<TS, false>(tile + (y + 3) * TS + x + 4);
+    }
+    __syncthreads();
+    for (int qi = lane; qi < nB; qi += 64) {
+      const int id = queue[qcap - 1 - qi], x = id & 127, y = id >> 7;
+      if (x < cw && y < ch) {
+        uint8_t* q = mm + (y + 1) * TS + x + 4;   // the dark side may have written this pixel
+        *q = (uint8_t)max((int)*q, fast_m_side<TS, true>(tile + (y + 3) * TS + x + 4));
+      }
+    }
   }
   __syncthreads();
 
@@ -472,9 +579,9 @@ __device__ __forceinline__ bool fast_pass(const uint8_t* tile, uint8_t* mm, uint
   for (int qi = lane; qi < nwork; qi += 64) {
     int x, y;
     if (overflow) { y = (int)(((float)qi + 0.5f) * rcw); x = qi - y * cw; }
-    else { const int id = queue[qi]; x = id & 127; y = id >> 7; }
+    else { const int id = queue[qi < nD ? qi : qcap - 1 - (qi - nD)]; x = id & 127; y = id >> 7; }
     const uint8_t* q = mm + (y + 1) * TS + x + 4;
-    const int m = q[0];
+    const int m = (x < cw && y < ch) ? q[0] : 0;   // queue entries outside the cell score nothing
     if (m > tlow) {
       const bool isMax = m > q[-1] && m > q[1] && m > q[-TS - 1] && m > q[-TS] && m > q[-TS + 1] &&
                          m > q[TS - 1] && m > q[TS] && m > q[TS + 1];
@@ -513,10 +620,12 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Plan* __restrict__ plan
   const int nwords = (np + 31) >> 5;
 
   uint8_t* tile = smem;                                   // fast_tile_rows x TS
-  uint8_t* mm = tile + plan->fast_tile_rows * TS;         // fast_mm_rows x TS
-  uint16_t* queue = (uint16_t*)(mm + plan->fast_mm_rows * TS);
+  uint8_t* half = tile + plan->fast_tile_rows * TS;       // the same pixels, halved (quick test)
+  uint8_t* mm = half;                                     // fast_mm_rows x TS, once the quick test is done
+  uint16_t* queue = (uint16_t*)(half + plan->fast_tile_rows * TS);
   uint32_t* bitsIni = (uint32_t*)(queue + plan->fast_qcap);
   uint32_t* bitsMin = bitsIni + plan->fast_words;
+  int* qcnt = (int*)(((uintptr_t)(bitsMin + plan->fast_words) + 7) & ~(uintptr_t)7);   // one 8-byte counter pair
 
   // ---- 1. tile: LDS (row r, col c) = level pixel (X0 - 4 + c, Y0 - 3 + r) ----
   {
@@ -538,9 +647,11 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Plan* __restrict__ plan
       o.z = __builtin_amdgcn_alignbyte(v.w, v.z, shift);
       o.w = __builtin_amdgcn_alignbyte(v4, v.w, shift);
       *(uint4*)(tile + r * TS + 16 * n) = o;
+      uint4 hv;
+      hv.x = (o.x >> 1) & 0x7f7f7f7fu; hv.y = (o.y >> 1) & 0x7f7f7f7fu;
+      hv.z = (o.z >> 1) & 0x7f7f7f7fu; hv.w = (o.w >> 1) & 0x7f7f7f7fu;
+      *(uint4*)(half + r * TS + 16 * n) = hv;
     }
-    const int mmq = ((ch + 2) * TS + 15) >> 4;
-    for (int i = lane; i < mmq; i += 64) ((uint4*)mm)[i] = make_uint4(0, 0, 0, 0);
     for (int i = lane; i < nwords; i += 64) { bitsIni[i] = 0; bitsMin[i] = 0; }
   }
   __syncthreads();
@@ -557,10 +668,22 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Plan* __restrict__ plan
   const float rcw = 1.0f / (float)cw;
   bool useIni;
   if (ini > mn && plan->fast_two_pass) {
-    useIni = fast_pass<TS>(tile, mm, queue, qcap, cw, ch, lane, ini, ini, bitsIni, 0, nullptr);
-    if (!useIni) (void)fast_pass<TS>(tile, mm, queue, qcap, cw, ch, lane, mn, mn, bitsMin, 0, nullptr);
+    useIni = fast_pass<TS>(tile, half, mm, queue, qcnt, qcap, cw, ch, lane, ini, ini, bitsIni, 0, nullptr);
+    if (!useIni) {
+      // the first pass's map of m lies where the halved tile was: make that again (the second
+      // pass clears the map and writes every score it needs afresh)
+      const int nq4 = (ch + 6) * (TS / 16);
+      for (int i = lane; i < nq4; i += 64) {
+        const uint4 o = ((const uint4*)tile)[i];
+        uint4 hv;
+        hv.x = (o.x >> 1) & 0x7f7f7f7fu; hv.y = (o.y >> 1) & 0x7f7f7f7fu;
+        hv.z = (o.z >> 1) & 0x7f7f7f7fu; hv.w = (o.w >> 1) & 0x7f7f7f7fu;
+        ((uint4*)half)[i] = hv;
+      }
+      (void)fast_pass<TS>(tile, half, mm, queue, qcnt, qcap, cw, ch, lane, mn, mn, bitsMin, 0, nullptr);
+    }
   } else {
-    useIni = fast_pass<TS>(tile, mm, queue, qcap, cw, ch, lane, min(ini, mn), ini, bitsIni, mn, bitsMin);
+    useIni = fast_pass<TS>(tile, half, mm, queue, qcnt, qcap, cw, ch, lane, min(ini, mn), ini, bitsIni, mn, bitsMin);
   }
   const uint32_t* bits = useIni ? bitsIni : bitsMin;
 
@@ -1603,8 +1726,8 @@ void launch_pyramid(const Plan& hp, const uint8_t* d_img, int istride, size_t if
 }
 
 size_t fast_lds_bytes(const Plan& hp, int ts) {
-  return (size_t)(hp.fast_tile_rows + hp.fast_mm_rows) * ts + (size_t)hp.fast_qcap * 2 +
-         (size_t)hp.fast_words * 8 + 16;
+  // tile + halved tile (the map of m reuses the latter: fast_mm_rows <= fast_tile_rows) + queue + masks
+  return (size_t)(2 * hp.fast_tile_rows) * ts + (size_t)hp.fast_qcap * 2 + (size_t)hp.fast_words * 8 + 8 + 16;
 }
 
 // cells of levels [l0, l1)
