@@ -421,6 +421,7 @@ int orbx_extractor::buildPlan(int W, int H) {
   hp.min_th = std::min(std::max(prm.min_th_fast, 0), 255);
   hp.max_batch = B;
   for (int i = 0; i < 16; ++i) hp.umax[i] = umax[i];
+  for (int i = 0; i < 16; ++i) hp.umax_packed |= (unsigned long long)(umax[i] & 15) << (4 * i);
 
   size_t pyrOff = 0, blurOff = 0;
   uint32_t candOff = 0, flatOff = 0;

@@ -1600,8 +1600,6 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Plan* __restrict_
   // the 31 x 31 patch goes through the same LDS window as the blurred one below
   __shared__ __align__(16) uint32_t sWin[16][DESC_WIN_DW];
   const int slotInBlock = (int)(threadIdx.x >> 6) * 4 + g;
-  const int u0 = 2 * j16 - 15, u1 = u0 + 1;
-  const int au0 = u0 < 0 ? -u0 : u0, au1 = u1 < 0 ? -u1 : u1;
   int m10 = 0, m01 = 0;
   {
     const int px0 = (cx + ORBX_EDGE - 15) & ~3;   // padded column of the window's first dword
@@ -1614,9 +1612,6 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Plan* __restrict_
       const U4A4 t = *(const U4A4*)(pbase + (size_t)r * ps + 16 * c3);
       st2[u] = make_uint4(t.x, t.y, t.z, t.w);
     }
-    int um[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) um[i] = plan->umax[i];
 #pragma unroll
     for (int u = 0; u < IC_STAGE; ++u) {
       const int idx = j16 + 16 * u;
@@ -1624,15 +1619,44 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Plan* __restrict_
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    const uint8_t* center = (const uint8_t*)sWin[slotInBlock] + 15 * (4 * WIN_ROW_DW) + (cx + ORBX_EDGE - px0);
+    // Lane j of the group sums patch rows v = 2j - 15 and 2j - 14 (the second one does not exist
+    // for j = 15: its mask is empty).  A row's 31 pixels u = -15 .. 15 start at byte `sh` of the
+    // window row; eight re-based dwords hold them (plus u = 16, always masked), the row's mask
+    // keeps |u| <= umax[|v|], and two 4-way byte dot products per dword give sum(I) and
+    // sum((u + 16) I).
+    const int sh = (cx + ORBX_EDGE - px0) - 15;   // 0..3
+    const unsigned long long umaxPacked = plan->umax_packed;
 #pragma unroll
-    for (int v = -15; v <= 15; ++v) {
-      const int lim = um[v < 0 ? -v : v];
-      const uint8_t* rp = center + v * (4 * WIN_ROW_DW);
-      const int a = au0 <= lim ? (int)rp[u0] : 0;
-      const int b = au1 <= lim ? (int)rp[u1] : 0;   // u1 = 16 never passes (lim <= 15)
-      m10 += __mul24(u0, a) + __mul24(u1, b);
-      m01 += __mul24(v, a + b);
+    for (int rr = 0; rr < 2; ++rr) {
+      const int r = 2 * j16 + rr;
+      const int v = r - 15;
+      const int av = v < 0 ? -v : v;
+      // umax[|v|] from the packed table (4 bits per row; row 16 does not exist: nothing passes),
+      // then per dword the bytes lo <= 4 i + k <= hi as a byte mask: two per-byte compares
+      // through bit 7 (no borrow: all operands are below 0x80), widened to 0xFF
+      const int lim = av < 16 ? (int)((umaxPacked >> (4 * av)) & 15u) : -1;
+      const uint32_t lo4 = (uint32_t)(15 - lim) * 0x01010101u, hi4 = ((uint32_t)(15 + lim) * 0x01010101u) | 0x80808080u;
+      uint32_t mk[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t ci = 0x03020100u + 0x04040404u * (uint32_t)i;
+        const uint32_t ok = ((ci | 0x80808080u) - lo4) & (hi4 - ci) & 0x80808080u;
+        mk[i] = lim < 0 ? 0u : (ok << 1) - (ok >> 7);
+      }
+      const uint4* rp = (const uint4*)&sWin[slotInBlock][r * WIN_ROW_DW];
+      const uint4 q0 = rp[0], q1 = rp[1], q2 = rp[2];
+      const uint32_t d[9] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x};
+      uint32_t sI = 0, sW = 0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t x = __builtin_amdgcn_alignbyte(d[i + 1], d[i], sh) & mk[i];
+        const uint32_t wk = (uint32_t)(4 * i + 1) | ((uint32_t)(4 * i + 2) << 8) | ((uint32_t)(4 * i + 3) << 16) |
+                            ((uint32_t)(4 * i + 4) << 24);
+        sI = __builtin_amdgcn_udot4(x, 0x01010101u, sI, false);
+        sW = __builtin_amdgcn_udot4(x, wk, sW, false);
+      }
+      m10 += (int)sW - 16 * (int)sI;
+      m01 += v * (int)sI;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -1660,7 +1684,9 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Plan* __restrict_
   }
   const float factorPI = (float)(3.1415926535897932384626433832795 / 180.0);
   const float rad = __fmul_rn(angle, factorPI);
-  const float a = (float)cos((double)rad), b = (float)sin((double)rad);
+  double sind, cosd;
+  sincos((double)rad, &sind, &cosd);
+  const float a = (float)cosd, b = (float)sind;
 #pragma unroll
   for (int u = 0; u < DESC_STAGE; ++u) {
     const int idx = j16 + 16 * u;
@@ -1677,15 +1703,17 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Plan* __restrict_
     const uint32_t ws[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const uint32_t w = ws[e];
+      const uint32_t w = ws[e];   // x0, y0, x1, y1 of test 16 j + 4 q + e
       const float x0 = (float)(int8_t)(w & 0xFF), y0 = (float)(int8_t)((w >> 8) & 0xFF);
       const float x1 = (float)(int8_t)((w >> 16) & 0xFF), y1 = (float)(int8_t)(w >> 24);
-      const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
-      const int q0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
-      const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
-      const int q1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-      const int t0 = bc[r0 * (4 * WIN_ROW_DW) + q0];
-      const int t1 = bc[r1 * (4 * WIN_ROW_DW) + q1];
+      // cvRound of the rotated coordinates (round half to even), then row * 48 + column; both are
+      // small integers held in floats, so the fused multiply-add is exact
+      const float r0 = rintf(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
+      const float q0 = rintf(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
+      const float r1 = rintf(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
+      const float q1 = rintf(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
+      const int t0 = bc[(int)__fmaf_rn(r0, (float)(4 * WIN_ROW_DW), q0)];
+      const int t1 = bc[(int)__fmaf_rn(r1, (float)(4 * WIN_ROW_DW), q1)];
       bits |= (t0 < t1 ? 1u : 0u) << (q * 4 + e);
     }
   }

@@ -92,6 +92,7 @@ struct Plan {
   int oct_keys_lds;      // keys per LDS key buffer of k_octree (0 = always use global memory)
   uint32_t oct_ws_bytes; // 0: node arrays in LDS; else bytes of global workspace per (frame, level)
   int umax[16];          // circular patch row half-widths (extractor.cc:448-462)
+  unsigned long long umax_packed;   // umax[v] in bits 4 v .. 4 v + 3
   LevelDesc lv[ORBX_MAX_LEVELS];
 };
 

@@ -287,6 +287,7 @@ static inline float __fmul_rn(float a, float b) { return a * b; }
 static inline float __fadd_rn(float a, float b) { return a + b; }
 static inline float __fsub_rn(float a, float b) { return a - b; }
 static inline float __fdiv_rn(float a, float b) { return a / b; }
+static inline float __fmaf_rn(float a, float b, float c) { return fmaf(a, b, c); }
 static inline int __float2int_rn(float v) { return (int)lrintf(v); }
 static inline int __float2int_rd(float v) { return (int)floorf(v); }
 static inline int __float2int_ru(float v) { return (int)ceilf(v); }
