@@ -151,9 +151,10 @@ def hamming_bench(torch, orbx, dev, world, rank, nq=1 << 20, nt_per_gpu=1_250_00
     t = torch.randint(0, 256, (nt_per_gpu, 32), dtype=torch.uint8, device=dev, generator=g)
     offset = rank * nt_per_gpu
     stream = torch.cuda.current_stream(dev).cuda_stream
+    sharded = world > 1 or os.environ.get("ORBX_BENCH_FORCE_SHARDED") == "1"   # the knob: one-rank communicator
     if world > 1:
         import torch.distributed as dist
-
+    if sharded:
         def run():
             return orbx.knn_match2_sharded(q, t, offset)
     else:
@@ -183,10 +184,31 @@ def hamming_bench(torch, orbx, dev, world, rank, nq=1 << 20, nt_per_gpu=1_250_00
            "train_rows_per_gpu": nt_per_gpu, "ms": sec * 1e3, "n_gpus": world,
            "roofline": {"bound": "valu", "achieved": pairs * 16 / 1e12, "peak": VALU_PEAK_LANE_OPS * world / 1e12,
                         "unit": "T lane-ops/s", "frac": pairs * 16 / (VALU_PEAK_LANE_OPS * world)}}
-    if world > 1:
-        out["exchange"] = {"collective": "ncclAllGather (in place)", "bytes_per_rank_sent": nq * 12,
-                           "bytes_per_rank_received": nq * 12 * world}
+    if sharded:
+        out["exchange"] = {"entry_point": "orbx_knn2_sharded", "collective": "ncclAllGather (in place)",
+                           "bytes_per_rank_sent": nq * 12, "bytes_per_rank_received": nq * 12 * world}
     return out
+
+
+def with_deadline(fn, seconds, dev, torch):
+    """fn() on a worker thread with a deadline.  A collective that never completes (a rank that
+    died, a fabric problem) must not take the headline line with it: after the deadline the caller
+    reports the leg as timed out and the process later leaves through os._exit."""
+    box = {}
+
+    def work():
+        try:
+            torch.cuda.set_device(dev)          # the current device is per thread
+            box["result"] = fn()
+        except Exception as e:                  # reported in the line, not raised
+            box["result"] = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    t = threading.Thread(target=work, daemon=True)
+    t.start()
+    t.join(seconds)
+    if t.is_alive():
+        return {"error": "no result after %d s" % seconds}, True
+    return box["result"], False
 
 
 def host_path_bench(torch, orbx, dev, local_rank, frames, n_frames=2048):
@@ -632,11 +654,10 @@ def main():
     ex.close()
     del d_imgs
     # the 2-NN leg runs on every rank (sharded when there are several)
+    stuck = False
     if not args.no_match:
-        try:
-            ham = hamming_bench(torch, orbx, dev, world, rank)
-        except Exception as e:   # the headline line must not be lost to a failure of a secondary leg
-            ham = {"error": "%s: %s" % (type(e).__name__, e)}
+        # the headline line must not be lost to a failure (or a hang) of a secondary leg
+        ham, stuck = with_deadline(lambda: hamming_bench(torch, orbx, dev, world, rank), 240, dev, torch)
         if out is not None:
             out["hamming"] = ham
     if rank == 0:
@@ -664,6 +685,8 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
+    if stuck:
+        os._exit(0)      # a collective is still pending on a worker thread: no orderly shutdown possible
     if world > 1:
         dist.barrier()   # the other ranks wait here while rank 0 finishes its single-rank legs
         dist.destroy_process_group()

@@ -131,13 +131,16 @@ class RcclComm:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         uid = np.zeros(128, np.uint8)
-        if self.rank == 0:
-            check(lib().orbx_rccl_unique_id(ptr(uid)), "orbx_rccl_unique_id")
+        st = lib().orbx_rccl_unique_id(ptr(uid)) if self.rank == 0 else 0
         if self.world > 1:
-            box = [uid.tobytes()]
+            # the status travels with the id, so that a failure on rank 0 is raised on every rank
+            # instead of leaving the others waiting for an id that never comes
+            box = [(int(st), uid.tobytes())]
             dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0,
                                        group=group)
-            uid = np.frombuffer(box[0], np.uint8).copy()
+            st, raw = box[0]
+            uid = np.frombuffer(raw, np.uint8).copy()
+        check(st, "orbx_rccl_unique_id")
         h = C.c_void_p()
         check(lib().orbx_rccl_comm_create(ptr(uid), self.world, self.rank, int(device_index), C.byref(h)),
               "orbx_rccl_comm_create")

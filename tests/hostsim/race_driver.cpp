@@ -115,6 +115,33 @@ int main(int argc, char** argv) {
   CHECK(orbx_extract_batch(right, NF, pr, W, H, W, 0, 0, kpsR.data(), descR.data(), cap, nR, monoR));
   fprintf(stderr, "race_driver: keypoints %d %d | %d %d\n", n[0], n[1], nR[0], nR[1]);
 
+  step("host batches in several groups: ordinary memory (staging threads) and page-locked memory");
+  {
+    setenv("ORBX_HOST_GROUP", "2", 1);     // read when the plan is built: 5 frames = 3 groups
+    orbx_params pg = {300, 1.2f, 4, 20, 7, 0, 5};
+    orbx_extractor* eg = nullptr;
+    CHECK(orbx_create(&pg, &eg));
+    const int capg = orbx_max_keypoints(eg);
+    const uint8_t* five[5] = {pl[0], pl[1 % NF], pl[0], pl[1 % NF], pl[0]};
+    std::vector<orbx_keypoint> kg((size_t)5 * capg);
+    std::vector<uint8_t> dg((size_t)5 * capg * 32);
+    int ng[5], mg[5];
+    CHECK(orbx_extract_batch(eg, 5, five, W, H, W, 0, 1000, kg.data(), dg.data(), capg, ng, mg));
+    void *hi = nullptr, *hk = nullptr, *hd = nullptr;
+    CHECK(orbx_host_alloc((size_t)5 * W * H, &hi));
+    CHECK(orbx_host_alloc((size_t)5 * capg * 28, &hk));
+    CHECK(orbx_host_alloc((size_t)5 * capg * 32, &hd));
+    const uint8_t* pin[5];
+    for (int f = 0; f < 5; ++f) {
+      memcpy((uint8_t*)hi + (size_t)f * W * H, five[f], (size_t)W * H);
+      pin[f] = (const uint8_t*)hi + (size_t)f * W * H;
+    }
+    CHECK(orbx_extract_batch(eg, 5, pin, W, H, W, 0, 1000, (orbx_keypoint*)hk, (uint8_t*)hd, capg, ng, mg));
+    CHECK(orbx_host_free(hi)); CHECK(orbx_host_free(hk)); CHECK(orbx_host_free(hd));
+    orbx_destroy(eg);
+    unsetenv("ORBX_HOST_GROUP");
+  }
+
   step("lapping-area 2-NN on the two extractions");
   {
     std::vector<uint32_t> li((size_t)cap * 2);
@@ -371,6 +398,11 @@ int main(int argc, char** argv) {
                            (uint32_t*)di + 2 * nq, (uint16_t*)dd + 2 * nq, nullptr));
     CHECK(orbx_top2_merge_device((const uint32_t*)di, (const uint16_t*)dd, 2, nq, (uint32_t*)dio, (uint16_t*)ddo,
                                  nullptr));
+    // the allocation-free form (partial results in the library's own device array), twice
+    CHECK(orbx_knn2_device_noalloc((const uint8_t*)dq, nq, (const uint8_t*)dt, nt, 0, (uint32_t*)dio, (uint16_t*)ddo,
+                                   nullptr));
+    CHECK(orbx_knn2_device_noalloc((const uint8_t*)dq, nq / 2, (const uint8_t*)dt, half, 7, (uint32_t*)dio,
+                                   (uint16_t*)ddo, nullptr));
     hipFree(dq); hipFree(dt); hipFree(di); hipFree(dd); hipFree(dio); hipFree(ddo);
   }
 
