@@ -284,6 +284,14 @@ struct orbx_extractor {
   size_t h_pyr_bytes = 0;
   bool h_pyr_valid = false;
 
+  // A batch that ran as two parts leaves its second part on lane[1].  The main stream is made to
+  // wait for it only when something other than the next equally split batch follows (a download,
+  // a derived stage, a synchronisation): back-to-back batches then run as two independent
+  // pipelines, each part following only its own predecessor, instead of every batch waiting for
+  // the previous one's slower half.
+  bool pendingJoin = false;
+  int pendingFrames = 0;       // frame count of the batch whose second part is still un-joined
+  int joinParts();
   int lastFrames = 0;
   bool profiling = false;
   hipEvent_t ev[ORBX_NUM_STAGES + 1] = {};
@@ -345,6 +353,10 @@ void orbx_extractor::freePlan() {
   if (!planned) return;
   (void)hipSetDevice(device);
   (void)hipStreamSynchronize(stream);
+  for (int k = 0; k < kLanes; ++k) if (lane[k]) (void)hipStreamSynchronize(lane[k]);   // a second part may still run
+  if (sIn) (void)hipStreamSynchronize(sIn);
+  if (sOut) (void)hipStreamSynchronize(sOut);
+  pendingJoin = false;
   for (void* t : d_taps) (void)hipFree(t);
   d_taps.clear();
   if (d_bowBlock) (void)hipFree(d_bowBlock);
@@ -654,11 +666,24 @@ int orbx_extractor::ensureHostStaging(bool pageableIn, bool pageableOut) {
   return ORBX_OK;
 }
 
+int orbx_extractor::joinParts() {
+  if (!pendingJoin) return ORBX_OK;
+  pendingJoin = false;
+  HIP_TRY(hipStreamWaitEvent(stream, evJoin[1], 0));
+  return ORBX_OK;
+}
+
 int orbx_extractor::run(const uint8_t* d_images, int istride, size_t iframe, int nframes, int lap0,
                         int lap1) {
   hipStream_t s = stream;
   const bool prof = profiling;
   lastParts = 0;
+  // the parts of this batch cover the same frames as those of the previous one only when the
+  // batch is split the same way; anything else first waits for the previous second part
+  if (pendingJoin && (prof || nframes != pendingFrames)) {
+    const int js = joinParts();
+    if (js != ORBX_OK) return js;
+  }
   if (prof) {
     // timing mode: one stream, stages back to back, HIP events around each stage
     HIP_TRY(hipEventRecord(ev[0], s));
@@ -695,7 +720,7 @@ int orbx_extractor::run(const uint8_t* d_images, int istride, size_t iframe, int
       hipStream_t m = odd ? lane[1] : s;
       // a part starts its pyramid when the previous part's pyramid is done
       if (k > 0) HIP_TRY(hipStreamWaitEvent(m, evPyr[k - 1], 0));
-      const int st = enqueuePart(k, m, odd ? lane[2] : lane[0], odd ? evForkB : evFork, odd ? evJoin[2] : evJoin[0],
+      const int st = enqueuePart(k, m, lane[0], odd ? evForkB : evFork, odd ? evJoin[2] : evJoin[0],
                                  f0, n, k + 1 < nparts ? evPyr[k] : nullptr, d_images, istride, iframe, lap0, lap1);
       if (st != ORBX_OK) return st;
       f0 += n;
@@ -703,7 +728,8 @@ int orbx_extractor::run(const uint8_t* d_images, int istride, size_t iframe, int
     lastParts = nparts;
     if (nparts > 1) {
       HIP_TRY(hipEventRecord(evJoin[1], lane[1]));
-      HIP_TRY(hipStreamWaitEvent(s, evJoin[1], 0));
+      pendingJoin = true;
+      pendingFrames = nframes;
     }
   }
   evValid = prof;
@@ -861,11 +887,17 @@ int orbx_max_keypoints(const orbx_extractor* ex) {
   return sum;
 }
 
-void* orbx_stream(orbx_extractor* ex) { return ex ? (void*)ex->stream : nullptr; }
+void* orbx_stream(orbx_extractor* ex) {
+  if (!ex) return nullptr;
+  // callers order their own work against this stream: it must cover everything enqueued so far
+  if (hipSetDevice(ex->device) == hipSuccess) (void)ex->joinParts();
+  return (void*)ex->stream;
+}
 
 int orbx_sync(orbx_extractor* ex) {
   if (!ex) return ORBX_ERR_BAD_ARG;
   if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  if (const int js_ = ex->joinParts()) return js_;
   hipError_t e = hipStreamSynchronize(ex->stream);
   if (e != hipSuccess) { ex->last_hip_error = e; return ORBX_ERR_HIP; }
   return ORBX_OK;
@@ -898,6 +930,7 @@ int orbx_batch_download(orbx_extractor* ex, int frame, orbx_keypoint* kps, uint8
                         int* n_out, int* mono_out) {
   if (!ex || !ex->planned || frame < 0 || frame >= ex->lastFrames) return ORBX_ERR_BAD_ARG;
   if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  if (const int js_ = ex->joinParts()) return js_;
   hipStream_t s = ex->stream;
   int nm[2];
   {
@@ -949,6 +982,7 @@ int orbx_extract_batch(orbx_extractor* ex, int n_frames, const uint8_t* const* i
   if (stride < width || cap < 0) return ORBX_ERR_BAD_ARG;
   if (n_frames > ex->prm.max_batch) return ORBX_ERR_BATCH;
   if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  if (const int js_ = ex->joinParts()) return js_;
   int st = ex->ensurePlan(width, height);
   if (st != ORBX_OK) { ex->freePlan(); return st; }
   auto& last_hip_error = ex->last_hip_error;
@@ -1037,7 +1071,7 @@ int orbx_extract_batch(orbx_extractor* ex, int n_frames, const uint8_t* const* i
     const bool odd = k & 1;
     hipStream_t ms = odd ? ex->lane[1] : ex->stream;
     HIP_TRY(hipStreamWaitEvent(ms, ex->evIn[b], 0));
-    st = ex->enqueuePart(b, ms, odd ? ex->lane[2] : ex->lane[0], odd ? ex->evForkB : ex->evFork,
+    st = ex->enqueuePart(b, ms, ex->lane[0], odd ? ex->evForkB : ex->evFork,
                          odd ? ex->evJoin[2] : ex->evJoin[0], f0, m, nullptr, ex->d_img, width, frameBytes,
                          lap0, lap1);
     if (st != ORBX_OK) return st;
@@ -1127,6 +1161,7 @@ int orbx_stereo_from_rgbd_batch_device(orbx_extractor* ex, int n_frames, const f
     return ORBX_ERR_BAD_ARG;
   if (n_frames > ex->gridFrames) return ORBX_ERR_BATCH;   // the undistorted keypoints come from the grid call
   if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  if (const int js_ = ex->joinParts()) return js_;
   auto& last_hip_error = ex->last_hip_error;
   const int st = ensure_stereo_buffers(ex);
   if (st != ORBX_OK) return st;
@@ -1146,6 +1181,7 @@ int orbx_stereo_match_batch_device(orbx_extractor* left, orbx_extractor* right, 
   if (n_frames > left->lastFrames || n_frames > right->lastFrames) return ORBX_ERR_BATCH;
   orbx_extractor* ex = left;
   if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  if (const int js_ = ex->joinParts()) return js_;
   auto& last_hip_error = ex->last_hip_error;
   {
     const int st = ensure_stereo_buffers(ex);
@@ -1161,6 +1197,7 @@ int orbx_stereo_match_batch_device(orbx_extractor* left, orbx_extractor* right, 
   }
   if (!ex->evStereo) HIP_TRY(hipEventCreateWithFlags(&ex->evStereo, hipEventDisableTiming));
   // the right extraction runs on its own stream: order this work after it
+  if (const int js_ = right->joinParts()) return js_;
   HIP_TRY(hipEventRecord(ex->evStereo, right->stream));
   HIP_TRY(hipStreamWaitEvent(ex->stream, ex->evStereo, 0));
   orbx::launch_stereo(ex->hp, ex->dp, ex->d_pyr, right->d_pyr, ex->d_kps, ex->d_desc, ex->d_n,
@@ -1189,6 +1226,7 @@ int orbx_stereo_download(orbx_extractor* left, int frame, float* uright, float* 
   if (!ex || !ex->planned || !ex->d_stURight || frame < 0 || frame >= ex->stereoFrames)
     return ORBX_ERR_BAD_ARG;
   if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  if (const int js_ = ex->joinParts()) return js_;
   auto& last_hip_error = ex->last_hip_error;
   hipStream_t s = ex->stream;
   int n = 0;
@@ -1220,10 +1258,12 @@ int orbx_lapping_knn2(orbx_extractor* left, orbx_extractor* right, int frame, ui
     return ORBX_ERR_BAD_ARG;
   orbx_extractor* ex = left;
   if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  if (const int js_ = ex->joinParts()) return js_;
   auto& last_hip_error = ex->last_hip_error;
   hipStream_t s = ex->stream;
   if (!ex->evStereo) HIP_TRY(hipEventCreateWithFlags(&ex->evStereo, hipEventDisableTiming));
   // the right extraction runs on its own stream: order this work after it
+  if (const int js_ = right->joinParts()) return js_;
   HIP_TRY(hipEventRecord(ex->evStereo, right->stream));
   HIP_TRY(hipStreamWaitEvent(s, ex->evStereo, 0));
   int h[4] = {0, 0, 0, 0};   // Nleft, monoLeft, Nright, monoRight
@@ -1271,6 +1311,7 @@ int orbx_frame_grid_batch_device(orbx_extractor* ex, int n_frames, const orbx_pi
   if (!(bounds[1] > bounds[0]) || !(bounds[3] > bounds[2])) return ORBX_ERR_BAD_ARG;
   if (n_frames > ex->lastFrames) return ORBX_ERR_BATCH;
   if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  if (const int js_ = ex->joinParts()) return js_;
   auto& last_hip_error = ex->last_hip_error;
   const int cap = ex->hp.kp_cap;
   if (cap >= 0xFFFF || orbx::frame_grid_lds_bytes(cap) > 64 * 1024) return ORBX_ERR_UNSUPPORTED;
@@ -1307,6 +1348,7 @@ int orbx_frame_grid_download(orbx_extractor* ex, int frame, orbx_keypoint* kps_u
                              int32_t* cell_entries, int cap, int* n_out) {
   if (!ex || !ex->planned || !ex->d_kpsUn || frame < 0 || frame >= ex->gridFrames) return ORBX_ERR_BAD_ARG;
   if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  if (const int js_ = ex->joinParts()) return js_;
   auto& last_hip_error = ex->last_hip_error;
   hipStream_t s = ex->stream;
   int n = 0;
@@ -1332,6 +1374,7 @@ int orbx_features_in_area(orbx_extractor* ex, int frame, const float* queries, i
     return ORBX_ERR_BAD_ARG;
   if (n_queries == 0) return ORBX_OK;
   if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  if (const int js_ = ex->joinParts()) return js_;
   auto& last_hip_error = ex->last_hip_error;
   hipStream_t s = ex->stream;
   float* dq = nullptr;
@@ -1405,6 +1448,7 @@ int search_by_projection(orbx_extractor* cur, int frame, int n_last, const uint8
   for (int i = 0; i < n_last; ++i)
     if (last_valid[i] && (last_octave[i] < 0 || last_octave[i] >= ex->prm.nlevels)) return ORBX_ERR_BAD_ARG;
   if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  if (const int js_ = ex->joinParts()) return js_;
   auto& last_hip_error = ex->last_hip_error;
   hipStream_t s = ex->stream;
   int n = 0;
@@ -1507,6 +1551,7 @@ int orbx_search_by_projection_points(orbx_extractor* f, int frame, int n_points,
   for (int i = 0; i < n_points; ++i)
     if (in_view[i] && (level[i] < 0 || level[i] >= ex->prm.nlevels)) return ORBX_ERR_BAD_ARG;
   if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  if (const int js_ = ex->joinParts()) return js_;
   auto& last_hip_error = ex->last_hip_error;
   hipStream_t s = ex->stream;
   int n = 0;
@@ -1575,6 +1620,7 @@ int orbx_search_for_initialization(orbx_extractor* f2, int frame2, int n1, const
   if (rounds) *rounds = 0;
   if (n1 == 0) return ORBX_OK;
   if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  if (const int js_ = ex->joinParts()) return js_;
   auto& last_hip_error = ex->last_hip_error;
   hipStream_t s = ex->stream;
   int n2 = 0;
@@ -1620,6 +1666,7 @@ int orbx_bow_transform_batch_device(orbx_extractor* ex, const orbx_vocabulary* v
   if (!ex || !ex->planned || !voc || n_frames <= 0 || levelsup < 0) return ORBX_ERR_BAD_ARG;
   if (n_frames > ex->lastFrames) return ORBX_ERR_BATCH;
   if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  if (const int js_ = ex->joinParts()) return js_;
   const orbx::VocDevice* vd = orbx::voc_device(voc, ex->device);
   if (!vd) return ORBX_ERR_BAD_ARG;   // vocabulary lives on another device
   auto& last_hip_error = ex->last_hip_error;
@@ -1655,6 +1702,7 @@ int orbx_bow_download(orbx_extractor* ex, int frame, uint32_t* word_ids, double*
   if (!ex || !ex->planned || !ex->d_bowBlock || frame < 0 || frame >= ex->bowFrames || cap < 0)
     return ORBX_ERR_BAD_ARG;
   if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  if (const int js_ = ex->joinParts()) return js_;
   auto& last_hip_error = ex->last_hip_error;
   hipStream_t s = ex->stream;
   const orbx::BowBuffers& b = ex->bow;
@@ -1704,6 +1752,7 @@ int orbx_search_by_bow(orbx_extractor* f, int frame, int n_kf, const uint8_t* kf
       if (kf_features[i] >= (uint32_t)n_kf) return ORBX_ERR_BAD_ARG;
   }
   if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  if (const int js_ = ex->joinParts()) return js_;
   auto& last_hip_error = ex->last_hip_error;
   hipStream_t s = ex->stream;
   int n = 0;
@@ -1766,6 +1815,7 @@ int orbx_debug_level_padded(orbx_extractor* ex, int frame, int level, uint8_t* d
       frame >= ex->lastFrames)
     return ORBX_ERR_BAD_ARG;
   if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  if (const int js_ = ex->joinParts()) return js_;
   const LevelDesc& L = ex->hp.lv[level];
   {
     hipError_t e = hipStreamSynchronize(ex->stream);
@@ -1782,6 +1832,7 @@ int orbx_pyramid(orbx_extractor* ex, int level, const uint8_t** padded, int* wid
   if (!ex || !ex->planned || !padded || level < 0 || level >= ex->hp.nlevels || ex->lastFrames < 1)
     return ORBX_ERR_BAD_ARG;
   if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  if (const int js_ = ex->joinParts()) return js_;
   auto& last_hip_error = ex->last_hip_error;
   // host mirror of frame 0's pyramid: all levels back to back in pinned memory, fetched together
   // on the first request after an extraction (eight transfers, one wait)
@@ -1816,6 +1867,7 @@ int orbx_debug_level_candidates(orbx_extractor* ex, int frame, int level, int32_
       frame >= ex->lastFrames || !n_out)
     return ORBX_ERR_BAD_ARG;
   if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  if (const int js_ = ex->joinParts()) return js_;
   const LevelDesc& L = ex->hp.lv[level];
   const int nc = L.ncx * L.ncy;
   std::vector<int> counts(nc);
@@ -1845,6 +1897,7 @@ int orbx_debug_level_selected(orbx_extractor* ex, int frame, int level, int32_t*
       frame >= ex->lastFrames || !n_out)
     return ORBX_ERR_BAD_ARG;
   if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  if (const int js_ = ex->joinParts()) return js_;
   const LevelDesc& L = ex->hp.lv[level];
   int n = 0;
   std::vector<uint32_t> keys(L.sel_cap);
@@ -1867,6 +1920,7 @@ int orbx_debug_level_blurred(orbx_extractor* ex, int frame, int level, uint8_t* 
       frame >= ex->lastFrames)
     return ORBX_ERR_BAD_ARG;
   if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  if (const int js_ = ex->joinParts()) return js_;
   const LevelDesc& L = ex->hp.lv[level];
   hipError_t e = hipStreamSynchronize(ex->stream);
   if (e == hipSuccess)
@@ -1911,6 +1965,7 @@ int orbx_stage_times(orbx_extractor* ex, float* ms, int n) {
 int orbx_detect_launch_times(orbx_extractor* ex, float* ms, int32_t* frames, int cap, int* n_launches) {
   if (!ex || !ms || !frames || !n_launches || ex->lastParts <= 0 || cap < ex->lastParts) return ORBX_ERR_BAD_ARG;
   if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  if (const int js_ = ex->joinParts()) return js_;
   hipError_t e = hipStreamSynchronize(ex->stream);
   for (int k = 0; k < ex->lastParts && e == hipSuccess; ++k) {
     e = hipEventElapsedTime(&ms[k], ex->evDet[k][0], ex->evDet[k][1]);

@@ -278,3 +278,41 @@ def test_host_batch_pipeline_groups(oracle, pinned, monkeypatch):
     from orb_slam3_amd._lib import lib as _l
     for h in holds:
         _l().orbx_host_free(h)
+
+
+def test_two_part_batches_back_to_back(oracle):
+    """Batches large enough to run as two parts on two streams, enqueued back to back without a
+    synchronisation in between (the second part of one batch may still run while the first part of
+    the next one starts), with different images per batch, a differently split batch in between,
+    and downloads right after the last call: every downloaded frame equals the oracle's result
+    for the image that the LAST call put at that position."""
+    import torch
+    from tests.conftest import TORCH_DEVICE
+    W, H, B = 376, 240, 256
+    params = (300, 1.2, 5, 20, 7)
+    base = [orbx.textured_frame(4000 + i, W, H) for i in range(6)]
+    want = {}
+    for i, img in enumerate(base):
+        st, rmono, rk, rd = oracle.Extractor(*params).extract(img, (0, 1000))
+        assert st == 0
+        want[i] = (rmono, rk, rd)
+
+    def batch(shift, n):
+        idx = [(f + shift) % len(base) for f in range(n)]
+        return idx, torch.from_numpy(np.stack([base[i] for i in idx])).to(TORCH_DEVICE)
+
+    ex = orbx.ORBextractor(*params, max_batch=B)
+    ia, da = batch(0, B)
+    ib, db = batch(1, B)
+    ic, dc = batch(2, 160)        # split differently (2 x 80): must wait for the previous second part
+    idd, dd = batch(3, B)
+    for d, n in ((da, B), (db, B), (dc, 160), (dd, B), (da, B), (db, B)):
+        ex.extract_batch_device(d.data_ptr(), n, W, H, W, (0, 1000))
+    for f in (0, 1, 127, 128, 129, 200, 255):
+        mono, k, dsc = ex.download(f)
+        rmono, rk, rd = want[ib[f]]
+        assert mono == rmono and len(k) == len(rk), f
+        for fld in ("x", "y", "size", "response", "octave"):
+            assert np.array_equal(k[fld], rk[fld]), (f, fld)
+        assert np.array_equal(dsc, rd), f
+    ex.close()
