@@ -792,6 +792,30 @@ const char* orbx_strerror(int status) {
   }
 }
 
+extern "C++" {
+namespace orbx {
+// Several entry points take short-lived device memory from the device's stream-ordered pool
+// (hipMallocAsync).  With the pool's default release threshold of zero every such allocation is
+// given back to the system at the next synchronisation and mapped again by the next call (close to
+// a millisecond each time); once per device the threshold is raised so that the pool keeps what it
+// has handed out.  The pool is HIP's per-device default pool; PyTorch's caching allocator does not
+// use it.
+void keep_pool_memory(int device) {
+  static std::mutex mu;
+  static bool done[64] = {};
+  if (device < 0 || device >= 64) return;
+  std::lock_guard<std::mutex> lk(mu);
+  if (done[device]) return;
+  done[device] = true;
+  hipMemPool_t pool = nullptr;
+  if (hipDeviceGetDefaultMemPool(&pool, device) != hipSuccess || !pool) { (void)hipGetLastError(); return; }
+  uint64_t keep = UINT64_MAX;
+  if (hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) != hipSuccess) (void)hipGetLastError();
+}
+}  // namespace orbx
+}  // extern "C++"
+using orbx::keep_pool_memory;
+
 int orbx_create(const orbx_params* p, orbx_extractor** out) {
   if (!p || !out) return ORBX_ERR_BAD_ARG;
   *out = nullptr;
@@ -811,6 +835,7 @@ int orbx_create(const orbx_params* p, orbx_extractor** out) {
     delete ex;
     return ORBX_ERR_UNSUPPORTED;
   }
+  if (hipSetDevice(ex->device) == hipSuccess) keep_pool_memory(ex->device);
   if (hipSetDevice(ex->device) != hipSuccess ||
       hipStreamCreateWithFlags(&ex->stream, hipStreamNonBlocking) != hipSuccess) {
     delete ex;

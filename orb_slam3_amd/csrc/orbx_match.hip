@@ -20,6 +20,7 @@
 #include "../../include/orbx.h"
 
 namespace orbx {
+void keep_pool_memory(int device);   // orbx_api.hip
 
 #define KNN_QPL 2          // queries per lane
 #define KNN_BLOCK 256
@@ -282,6 +283,10 @@ static int knn2_launch(const uint8_t* d_q, int nq, const uint8_t* d_t, int64_t n
   int st = knn2_cut(nq, nt, (size_t)-1, &c);
   if (st != ORBX_OK) return st;
   uint8_t* partial = nullptr;
+  if (c.segs > 1) {
+    int dev = -1;
+    if (hipGetDevice(&dev) == hipSuccess) orbx::keep_pool_memory(dev);   // once per device
+  }
   if (c.segs > 1 &&
       hipMallocAsync((void**)&partial, align256((size_t)c.segs * nq * 8) + (size_t)c.segs * nq * 4, s) != hipSuccess)
     return ORBX_ERR_HIP;

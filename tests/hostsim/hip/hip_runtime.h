@@ -80,6 +80,11 @@ template <class T> inline hipError_t hipGetSymbolAddress(void** p, const T& symb
 extern "C" {
 hipError_t hipMalloc(void** p, size_t n);
 hipError_t hipFree(void* p);
+struct hostsim_mempool;
+typedef hostsim_mempool* hipMemPool_t;
+enum hipMemPoolAttr { hipMemPoolAttrReleaseThreshold = 4 };
+hipError_t hipDeviceGetDefaultMemPool(hipMemPool_t* pool, int device);
+hipError_t hipMemPoolSetAttribute(hipMemPool_t pool, hipMemPoolAttr attr, void* value);
 hipError_t hipMallocAsync(void** p, size_t n, hipStream_t s);
 hipError_t hipFreeAsync(void* p, hipStream_t s);
 hipError_t hipHostMalloc(void** p, size_t n, unsigned flags);

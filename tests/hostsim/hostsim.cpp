@@ -621,6 +621,8 @@ hipError_t hipFree(void* p) {
   if (!p) return hipSuccess;
   return hostsim::guarded_free(p) ? hipSuccess : hipErrorInvalidValue;
 }
+hipError_t hipDeviceGetDefaultMemPool(hipMemPool_t* pool, int) { *pool = nullptr; return hipErrorInvalidValue; }
+hipError_t hipMemPoolSetAttribute(hipMemPool_t, hipMemPoolAttr, void*) { return hipSuccess; }
 hipError_t hipMallocAsync(void** p, size_t n, hipStream_t) { return hipMalloc(p, n); }
 hipError_t hipFreeAsync(void* p, hipStream_t) { return hipFree(p); }
 // page-locked host allocations are remembered so that hipPointerGetAttributes can tell them
