@@ -289,6 +289,7 @@ struct orbx_extractor {
   // a derived stage, a synchronisation): back-to-back batches then run as two independent
   // pipelines, each part following only its own predecessor, instead of every batch waiting for
   // the previous one's slower half.
+  bool pyrWait = true;         // timing knob ORBX_PYR_WAIT: a part's pyramid waits for the previous part's
   bool pendingJoin = false;
   int pendingFrames = 0;       // frame count of the batch whose second part is still un-joined
   int joinParts();
@@ -719,7 +720,7 @@ int orbx_extractor::run(const uint8_t* d_images, int istride, size_t iframe, int
       const bool odd = k & 1;
       hipStream_t m = odd ? lane[1] : s;
       // a part starts its pyramid when the previous part's pyramid is done
-      if (k > 0) HIP_TRY(hipStreamWaitEvent(m, evPyr[k - 1], 0));
+      if (k > 0 && pyrWait) HIP_TRY(hipStreamWaitEvent(m, evPyr[k - 1], 0));
       const int st = enqueuePart(k, m, lane[0], odd ? evForkB : evFork, odd ? evJoin[2] : evJoin[0],
                                  f0, n, k + 1 < nparts ? evPyr[k] : nullptr, d_images, istride, iframe, lap0, lap1);
       if (st != ORBX_OK) return st;
@@ -836,6 +837,7 @@ int orbx_create(const orbx_params* p, orbx_extractor** out) {
     return ORBX_ERR_UNSUPPORTED;
   }
   if (hipSetDevice(ex->device) == hipSuccess) keep_pool_memory(ex->device);
+  if (const char* e = std::getenv("ORBX_PYR_WAIT")) ex->pyrWait = e[0] != '0';
   if (hipSetDevice(ex->device) != hipSuccess ||
       hipStreamCreateWithFlags(&ex->stream, hipStreamNonBlocking) != hipSuccess) {
     delete ex;

@@ -1560,7 +1560,9 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
   return a;
 }
 
-// 16 lanes per keypoint, 4 keypoints per wave, 16 per block.
+// 16 lanes per keypoint, 4 keypoints per wave, one wave per workgroup: a one-wave workgroup with
+// 7 KB of LDS finds a place on a CU that the detection kernel of the batch's other part keeps
+// full of small workgroups; four-wave workgroups with 28 KB waited for most of that kernel's run.
 //  * moments: lane j of a group owns patch columns u = 2j-15 and 2j-14 and walks the
 //    31 rows of the patch, which is staged in LDS by row-wise 16-byte loads;
 //  * descriptor: lane j evaluates tests 16j .. 16j+15 = descriptor bytes 2j, 2j+1.
@@ -1572,7 +1574,7 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 #define DESC_STAGE 7                    // 16-byte chunks per lane (16 lanes per keypoint)
 #define IC_CHUNKS (31 * 3)
 #define IC_STAGE 6
-__global__ __launch_bounds__(256) void k_orient_describe(const Plan* __restrict__ plan,
+__global__ __launch_bounds__(64) void k_orient_describe(const Plan* __restrict__ plan,
                                                          const uint8_t* __restrict__ pyr,
                                                          const uint8_t* __restrict__ blur,
                                                          const WorkItem* __restrict__ work,
@@ -1587,7 +1589,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Plan* __restrict_
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, j16 = lane & 15;
   const int n = nOut[f];
-  const int kbase = ((unit - fr * nblk) * 4 + (threadIdx.x >> 6)) * 4;
+  const int kbase = (unit - fr * nblk) * 4;
   if (kbase >= n) return;
   const int k = kbase + g;
   const bool valid = k < n;
@@ -1598,8 +1600,8 @@ __global__ __launch_bounds__(256) void k_orient_describe(const Plan* __restrict_
 
   // ---- IC_Angle on the un-blurred level (extractor.cc:75-99) ----------------
   // the 31 x 31 patch goes through the same LDS window as the blurred one below
-  __shared__ __align__(16) uint32_t sWin[16][DESC_WIN_DW];
-  const int slotInBlock = (int)(threadIdx.x >> 6) * 4 + g;
+  __shared__ __align__(16) uint32_t sWin[4][DESC_WIN_DW];
+  const int slotInBlock = g;
   int m10 = 0, m01 = 0;
   {
     const int px0 = (cx + ORBX_EDGE - 15) & ~3;   // padded column of the window's first dword
@@ -1813,8 +1815,8 @@ void launch_blur(const Plan& hp, const Plan* dp, const uint8_t* d_pyr, uint8_t* 
 void launch_describe(const Plan& hp, const Plan* dp, const uint8_t* d_pyr, const uint8_t* d_blur,
                      const WorkItem* d_work, const int* d_n, float* d_kps, uint8_t* d_desc,
                      int f0, int nframes, hipStream_t s) {
-  const int nblk = (hp.kp_cap + 15) / 16, nunits = nblk * nframes, chunk = (nunits + 7) / 8;
-  hipLaunchKernelGGL(k_orient_describe, dim3(8 * chunk), dim3(256), 0, s, dp, d_pyr, d_blur, d_work,
+  const int nblk = (hp.kp_cap + 3) / 4, nunits = nblk * nframes, chunk = (nunits + 7) / 8;
+  hipLaunchKernelGGL(k_orient_describe, dim3(8 * chunk), dim3(64), 0, s, dp, d_pyr, d_blur, d_work,
                      d_n, d_kps, d_desc, f0, nblk, nunits, chunk);
 }
 
