@@ -514,6 +514,13 @@ int orbx_extractor::buildPlan(int W, int H) {
   {
     const char* e = std::getenv("ORBX_FAST_SINGLE_PASS");   // timing knob, results do not change
     hp.fast_two_pass = (e && e[0] == '1') ? 0 : 1;
+    hp.blur_waves = 1;
+    if (const char* bw = std::getenv("ORBX_BLUR_WAVES")) hp.blur_waves = std::atoi(bw) == 4 ? 4 : 1;
+    hp.pyr_waves = 2;
+    if (const char* pw = std::getenv("ORBX_PYR_WAVES")) {
+      const int v = std::atoi(pw);
+      if (v == 1 || v == 2 || v == 4) hp.pyr_waves = v;
+    }
   }
   hp.oct_nodes_cap = nodesCap;
   hp.oct_cells_max = cellsMax;

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t* __restrict__ 
   const int ghi = (W - 1) / 16;
   if ((int)blockIdx.x < nbx) {
     const int g = blockIdx.x * 64 + threadIdx.x;
-    const int py0 = (blockIdx.y * 4 + threadIdx.y) * L0_ROWS;
+    const int py0 = (blockIdx.y * blockDim.y + threadIdx.y) * L0_ROWS;
     if (g < 2 || g > ghi) return;
     const int P = g * 16;
     uint8_t* fdst = dst + (size_t)f * dplane + P;
@@ -118,10 +118,10 @@ __global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t* __restrict__ 
     const int cr0 = 4 * (ghi + 1);
     const int nright = (W + 2 * ORBX_EDGE + 3) / 4 - cr0;
     const int nb = 8 + nright;
-    const int rows = 4 * L0_ROWS;
+    const int rows = (int)blockDim.y * L0_ROWS;
     const int tid = threadIdx.y * 64 + threadIdx.x;
     const float rnb = 1.0f / (float)nb;
-    for (int t = tid; t < rows * nb; t += 256) {
+    for (int t = tid; t < rows * nb; t += 64 * (int)blockDim.y) {
       const int r = (int)(((float)t + 0.5f) * rnb);
       const int j = t - r * nb;
       const int py = blockIdx.y * rows + r;
@@ -188,13 +188,13 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const uint8_t* __restrict__ 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
   const int f = blockIdx.z + f0;
   constexpr int rowsPerWave = 4 * GROUPS;
-  constexpr int rowsPerBlock = 4 * rowsPerWave;
+  const int rowsPerBlock = (int)blockDim.y * rowsPerWave;
   if ((int)blockIdx.x >= nbx) {
     // border block: one lane per (row, border dword); taps straight from the tables,
     // source bytes straight from the (cache-resident) source plane
     const uint8_t* roi = src + (size_t)f * splane + (size_t)ORBX_EDGE * sstride + ORBX_EDGE;
     const float rnb = 1.0f / (float)nbc;
-    for (int t = wave * 64 + lane; t < rowsPerBlock * nbc; t += 256) {
+    for (int t = wave * 64 + lane; t < rowsPerBlock * nbc; t += 64 * (int)blockDim.y) {
       const int r = (int)(((float)t + 0.5f) * rnb);
       const int py = blockIdx.y * rowsPerBlock + r;
       if (py >= prows) break;
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const uint8_t* __restrict__ 
   }
   const uint32_t keep = cr.nvalid >= 4 ? 0xFFFFFFFFu : ((1u << (8 * cr.nvalid)) - 1u);
   uint8_t* dcol = dst + (size_t)f * dplane + 4 * c;
-  const int pyBase = (blockIdx.y * 4 + wave) * rowsPerWave;
+  const int pyBase = (blockIdx.y * (int)blockDim.y + wave) * rowsPerWave;
   if (pyBase >= prows) return;
   // the row taps of all steps first: wave-uniform, read before any store so that they can
   // come through the scalar cache
@@ -1466,7 +1466,10 @@ __global__ __launch_bounds__(256) void k_blur(const Plan* __restrict__ plan,
                                               const uint8_t* __restrict__ pyr,
                                               uint8_t* __restrict__ blur, int f0, int ntiles,
                                               int nunits, int chunk) {
-  const int unit = xcd_contiguous_unit(chunk);
+  // a workgroup is the four 64-row bands of a tile (256 threads) or one of them (64 threads)
+  const int wpb = (int)blockDim.x >> 6;
+  const int u = xcd_contiguous_unit(chunk);
+  const int unit = wpb == 4 ? u : u >> 2;
   if (unit >= nunits) return;
   const int fr = unit / ntiles;
   const int f = fr + f0;
@@ -1476,7 +1479,7 @@ __global__ __launch_bounds__(256) void k_blur(const Plan* __restrict__ plan,
   const LevelDesc& L = plan->lv[l];
   const int t = tg - L.tile_first;
   const int tyi = t / L.tiles_x, txi = t - tyi * L.tiles_x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wpb == 4 ? (int)(threadIdx.x >> 6) : (u & 3);
   const int x0 = txi * 256 + lane * 4;
   const int y0 = (tyi * 4 + wave) * BLUR_BAND;
   if (x0 >= L.w || y0 >= L.h) return;
@@ -1731,11 +1734,15 @@ __global__ __launch_bounds__(64) void k_orient_describe(const Plan* __restrict__
 // ---------------------------------------------------------------------------
 void launch_pyramid(const Plan& hp, const uint8_t* d_img, int istride, size_t iframe, uint8_t* d_pyr,
                     int f0, int nframes, hipStream_t s) {
-  const dim3 blk(64, 4);
+  // waves per workgroup (1, 2 or 4): alone on the chip the stage is cheapest with fat workgroups
+  // (fewer dispatches); beside the other part's detection kernel, which keeps the CUs full of
+  // one-wave workgroups, a one-wave workgroup is placed as soon as a single wave slot frees
+  const int wpb = hp.pyr_waves;
+  const dim3 blk(64, wpb);
   {
     const LevelDesc& L = hp.lv[0];
     const int nbx = (L.pstride / 16 + 63) / 64;
-    dim3 grid(nbx + 1, (L.prows + 4 * L0_ROWS - 1) / (4 * L0_ROWS), nframes);
+    dim3 grid(nbx + 1, (L.prows + wpb * L0_ROWS - 1) / (wpb * L0_ROWS), nframes);
     hipLaunchKernelGGL(k_pyr_level0, grid, blk, 0, s, d_img, hp.W, hp.H, istride, iframe,
                        d_pyr + L.pyr_off, L.pstride, L.prows, L.pyr_plane, nbx, f0);
   }
@@ -1746,7 +1753,7 @@ void launch_pyramid(const Plan& hp, const uint8_t* d_img, int istride, size_t if
     // rows per wave: as many 4-row steps (up to 4) as still leave the chip about two rounds of waves
     int groups = 4;
     while (groups > 1 && (long long)nbx * ((L.prows + 4 * groups - 1) / (4 * groups)) * nframes < 16384) groups >>= 1;
-    dim3 grid(nbx + (L.n_bcols > 0 ? 1 : 0), (L.prows + 16 * groups - 1) / (16 * groups), nframes);
+    dim3 grid(nbx + (L.n_bcols > 0 ? 1 : 0), (L.prows + 4 * wpb * groups - 1) / (4 * wpb * groups), nframes);
     auto kern = groups == 4 ? k_pyr_resize<4> : groups == 2 ? k_pyr_resize<2> : k_pyr_resize<1>;
     hipLaunchKernelGGL(kern, grid, blk, 0, s, d_pyr + S.pyr_off,
                        S.pstride, S.pyr_plane, d_pyr + L.pyr_off, L.pstride, L.prows, L.pyr_plane,
@@ -1807,9 +1814,16 @@ void launch_assemble(const Plan& hp, const Plan* dp, const uint32_t* d_sel, cons
 
 void launch_blur(const Plan& hp, const Plan* dp, const uint8_t* d_pyr, uint8_t* d_blur, int f0,
                  int nframes, hipStream_t s) {
-  const int nunits = hp.tiles_per_frame * nframes, chunk = (nunits + 7) / 8;
-  hipLaunchKernelGGL(k_blur, dim3(8 * chunk), dim3(256), 0, s, dp, d_pyr, d_blur, f0,
-                     hp.tiles_per_frame, nunits, chunk);
+  const int nunits = hp.tiles_per_frame * nframes;
+  if (hp.blur_waves == 4) {
+    const int chunk = (nunits + 7) / 8;
+    hipLaunchKernelGGL(k_blur, dim3(8 * chunk), dim3(256), 0, s, dp, d_pyr, d_blur, f0, hp.tiles_per_frame, nunits,
+                       chunk);
+  } else {
+    const int chunk = (4 * nunits + 7) / 8;
+    hipLaunchKernelGGL(k_blur, dim3(8 * chunk), dim3(64), 0, s, dp, d_pyr, d_blur, f0, hp.tiles_per_frame, nunits,
+                       chunk);
+  }
 }
 
 void launch_describe(const Plan& hp, const Plan* dp, const uint8_t* d_pyr, const uint8_t* d_blur,

@@ -87,6 +87,8 @@ struct Plan {
   // 1: detect at iniThFAST first and at minThFAST only in cells that found nothing; 0: one pass
   // at the lower threshold that serves both (same results; kept switchable for timing)
   int fast_two_pass;
+  int blur_waves;        // waves per workgroup of the blur kernel, 4 or 1 (timing knob)
+  int pyr_waves;         // waves per workgroup of the pyramid kernels (timing knob; results do not change)
   int oct_nodes_cap;     // quadtree node slots (max over levels)
   int oct_cells_max;     // max cells in one level
   int oct_keys_lds;      // keys per LDS key buffer of k_octree (0 = always use global memory)
