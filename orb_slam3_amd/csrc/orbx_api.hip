@@ -221,8 +221,12 @@ struct orbx_extractor {
   static const int kSplitMin = 128;   // frames per half below which a batch is not split
   hipStream_t lane[kLanes] = {};
   hipEvent_t evFork = nullptr, evJoin[kLanes] = {};
-  static const int kMaxParts = 2;     // more parts measured slower (shorter kernels, longer tails)
+  static const int kMaxParts = 3;
+  int maxParts = 2;                   // parts a batch is cut into at most (timing knob ORBX_PARTS)
+  int blurPlace = 0;                  // blur: 0 after the quadtree on the part's stream, 1 beside it on the
+                                      // side stream, 2 before it (timing knob ORBX_SIDE_BLUR)
   hipEvent_t evStart = nullptr, evForkB = nullptr, evPyr[kMaxParts] = {};
+  hipEvent_t evForkP[kMaxParts] = {}, evJoinP[kMaxParts] = {}, evDone[kMaxParts] = {};
   hipError_t last_hip_error = hipSuccess;
 
   // plan for the current image size
@@ -292,13 +296,14 @@ struct orbx_extractor {
   bool pyrWait = true;         // timing knob ORBX_PYR_WAIT: a part's pyramid waits for the previous part's
   bool pendingJoin = false;
   int pendingFrames = 0;       // frame count of the batch whose second part is still un-joined
+  int pendingParts = 0;        // and the number of its parts
   int joinParts();
   int lastFrames = 0;
   bool profiling = false;
   hipEvent_t ev[ORBX_NUM_STAGES + 1] = {};
   // normal schedule: events around the detection kernel of every part of the last call
-  hipEvent_t evDet[2][2] = {};
-  int detFrames[2] = {0, 0};
+  hipEvent_t evDet[kMaxParts][2] = {};
+  int detFrames[kMaxParts] = {};
   int lastParts = 0;
   bool evValid = false;
 
@@ -677,7 +682,7 @@ int orbx_extractor::ensureHostStaging(bool pageableIn, bool pageableOut) {
 int orbx_extractor::joinParts() {
   if (!pendingJoin) return ORBX_OK;
   pendingJoin = false;
-  HIP_TRY(hipStreamWaitEvent(stream, evJoin[1], 0));
+  for (int k = 1; k < pendingParts; ++k) HIP_TRY(hipStreamWaitEvent(stream, evDone[k], 0));
   return ORBX_OK;
 }
 
@@ -717,27 +722,27 @@ int orbx_extractor::run(const uint8_t* d_images, int istride, size_t iframe, int
     // starting one stage behind the previous one, so that the latency-bound pyramid of a part
     // overlaps the VALU-bound detection of the part before it, and its detection overlaps
     // that part's quadtree and descriptors.
-    const int nparts = std::max(1, std::min(kMaxParts, nframes / kSplitMin));
+    const int nparts = std::max(1, std::min(maxParts, nframes / kSplitMin));
     if (nparts > 1) {
-      HIP_TRY(hipEventRecord(evStart, s));            // the second stream follows earlier work on s
-      HIP_TRY(hipStreamWaitEvent(lane[1], evStart, 0));
+      HIP_TRY(hipEventRecord(evStart, s));            // the other part streams follow earlier work on s
+      for (int k = 1; k < nparts; ++k) HIP_TRY(hipStreamWaitEvent(lane[k], evStart, 0));
     }
     for (int k = 0, f0 = 0; k < nparts; ++k) {
       const int n = (nframes - f0) / (nparts - k);
-      const bool odd = k & 1;
-      hipStream_t m = odd ? lane[1] : s;
+      hipStream_t m = k == 0 ? s : lane[k];
       // a part starts its pyramid when the previous part's pyramid is done
       if (k > 0 && pyrWait) HIP_TRY(hipStreamWaitEvent(m, evPyr[k - 1], 0));
-      const int st = enqueuePart(k, m, lane[0], odd ? evForkB : evFork, odd ? evJoin[2] : evJoin[0],
-                                 f0, n, k + 1 < nparts ? evPyr[k] : nullptr, d_images, istride, iframe, lap0, lap1);
+      const int st = enqueuePart(k, m, lane[0], evForkP[k], evJoinP[k], f0, n, k + 1 < nparts ? evPyr[k] : nullptr,
+                                 d_images, istride, iframe, lap0, lap1);
       if (st != ORBX_OK) return st;
       f0 += n;
     }
     lastParts = nparts;
     if (nparts > 1) {
-      HIP_TRY(hipEventRecord(evJoin[1], lane[1]));
+      for (int k = 1; k < nparts; ++k) HIP_TRY(hipEventRecord(evDone[k], lane[k]));
       pendingJoin = true;
       pendingFrames = nframes;
+      pendingParts = nparts;
     }
   }
   evValid = prof;
@@ -757,14 +762,18 @@ int orbx_extractor::enqueuePart(int pk, hipStream_t m, hipStream_t side, hipEven
   orbx::launch_fast(hp, dp, d_pyr, d_cand, d_cellCount, 0, hp.nlevels, f0, n, m);
   HIP_TRY(hipEventRecord(evDet[pk][1], m));
   detFrames[pk] = n;
-  HIP_TRY(hipEventRecord(fork, m));
-  HIP_TRY(hipStreamWaitEvent(side, fork, 0));
-  orbx::launch_blur(hp, dp, d_pyr, d_blur, f0, n, side);
-  HIP_TRY(hipEventRecord(join, side));
+  if (blurPlace == 2) orbx::launch_blur(hp, dp, d_pyr, d_blur, f0, n, m);
+  if (blurPlace == 1) {
+    HIP_TRY(hipEventRecord(fork, m));
+    HIP_TRY(hipStreamWaitEvent(side, fork, 0));
+    orbx::launch_blur(hp, dp, d_pyr, d_blur, f0, n, side);
+    HIP_TRY(hipEventRecord(join, side));
+  }
   orbx::launch_octree(hp, dp, d_cand, d_cellCount, d_flatA, d_flatB, d_sel, d_selCount, d_octws, 0,
                       hp.nlevels, f0, n, m);
   orbx::launch_assemble(hp, dp, d_sel, d_selCount, lap0, lap1, d_kps, d_work, d_n, d_mono, f0, n, m);
-  HIP_TRY(hipStreamWaitEvent(m, join, 0));
+  if (blurPlace == 1) HIP_TRY(hipStreamWaitEvent(m, join, 0));
+  if (blurPlace == 0) orbx::launch_blur(hp, dp, d_pyr, d_blur, f0, n, m);
   orbx::launch_describe(hp, dp, d_pyr, d_blur, d_work, d_n, d_kps, d_desc, f0, n, m);
   return ORBX_OK;
 }
@@ -852,13 +861,24 @@ int orbx_create(const orbx_params* p, orbx_extractor** out) {
   }
   for (int i = 0; i <= ORBX_NUM_STAGES; ++i)
     if (hipEventCreate(&ex->ev[i]) != hipSuccess) { orbx_destroy(ex); return ORBX_ERR_NO_DEVICE; }
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 2 * orbx_extractor::kMaxParts; ++i)
     if (hipEventCreate(&ex->evDet[i >> 1][i & 1]) != hipSuccess) { orbx_destroy(ex); return ORBX_ERR_NO_DEVICE; }
   bool ok = hipEventCreateWithFlags(&ex->evFork, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&ex->evStart, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&ex->evForkB, hipEventDisableTiming) == hipSuccess;
   for (int k = 0; k < orbx_extractor::kMaxParts && ok; ++k)
-    ok = hipEventCreateWithFlags(&ex->evPyr[k], hipEventDisableTiming) == hipSuccess;
+    ok = hipEventCreateWithFlags(&ex->evPyr[k], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&ex->evForkP[k], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&ex->evJoinP[k], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&ex->evDone[k], hipEventDisableTiming) == hipSuccess;
+  if (const char* e = std::getenv("ORBX_PARTS")) {
+    const int v = std::atoi(e);
+    if (v >= 1 && v <= orbx_extractor::kMaxParts) ex->maxParts = v;
+  }
+  if (const char* e = std::getenv("ORBX_SIDE_BLUR")) {
+    const int v = std::atoi(e);
+    if (v >= 0 && v <= 2) ex->blurPlace = v;
+  }
   for (int k = 0; k < orbx_extractor::kLanes && ok; ++k)
     ok = hipStreamCreateWithFlags(&ex->lane[k], hipStreamNonBlocking) == hipSuccess &&
          hipEventCreateWithFlags(&ex->evJoin[k], hipEventDisableTiming) == hipSuccess;
@@ -878,14 +898,19 @@ void orbx_destroy(orbx_extractor* ex) {
   (void)hipSetDevice(ex->device);
   ex->freePlan();
   for (int i = 0; i <= ORBX_NUM_STAGES; ++i) if (ex->ev[i]) (void)hipEventDestroy(ex->ev[i]);
-  for (int i = 0; i < 4; ++i) if (ex->evDet[i >> 1][i & 1]) (void)hipEventDestroy(ex->evDet[i >> 1][i & 1]);
+  for (int i = 0; i < 2 * orbx_extractor::kMaxParts; ++i) if (ex->evDet[i >> 1][i & 1]) (void)hipEventDestroy(ex->evDet[i >> 1][i & 1]);
   for (int k = 0; k < orbx_extractor::kLanes; ++k) {
     if (ex->lane[k]) { (void)hipStreamSynchronize(ex->lane[k]); (void)hipStreamDestroy(ex->lane[k]); }
     if (ex->evJoin[k]) (void)hipEventDestroy(ex->evJoin[k]);
   }
   if (ex->evFork) (void)hipEventDestroy(ex->evFork);
   if (ex->evStart) (void)hipEventDestroy(ex->evStart);
-  for (int k = 0; k < orbx_extractor::kMaxParts; ++k) if (ex->evPyr[k]) (void)hipEventDestroy(ex->evPyr[k]);
+  for (int k = 0; k < orbx_extractor::kMaxParts; ++k) {
+    if (ex->evPyr[k]) (void)hipEventDestroy(ex->evPyr[k]);
+    if (ex->evForkP[k]) (void)hipEventDestroy(ex->evForkP[k]);
+    if (ex->evJoinP[k]) (void)hipEventDestroy(ex->evJoinP[k]);
+    if (ex->evDone[k]) (void)hipEventDestroy(ex->evDone[k]);
+  }
   if (ex->evForkB) (void)hipEventDestroy(ex->evForkB);
   if (ex->evStereo) (void)hipEventDestroy(ex->evStereo);
   for (int i = 0; i < 2; ++i) {
@@ -1105,8 +1130,7 @@ int orbx_extract_batch(orbx_extractor* ex, int n_frames, const uint8_t* const* i
     const bool odd = k & 1;
     hipStream_t ms = odd ? ex->lane[1] : ex->stream;
     HIP_TRY(hipStreamWaitEvent(ms, ex->evIn[b], 0));
-    st = ex->enqueuePart(b, ms, ex->lane[0], odd ? ex->evForkB : ex->evFork,
-                         odd ? ex->evJoin[2] : ex->evJoin[0], f0, m, nullptr, ex->d_img, width, frameBytes,
+    st = ex->enqueuePart(b, ms, ex->lane[0], ex->evForkP[b], ex->evJoinP[b], f0, m, nullptr, ex->d_img, width, frameBytes,
                          lap0, lap1);
     if (st != ORBX_OK) return st;
     HIP_TRY(hipEventRecord(ex->evComp[b], ms));
