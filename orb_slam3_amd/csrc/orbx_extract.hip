@@ -341,13 +341,14 @@ __device__ __forceinline__ int fast_m(const uint8_t* c) {
   return max(max(best_dark, -best_bright), 0);
 }
 
-// The largest m' such that nine contiguous ring pixels are all darker than the centre by more
-// than m' - 1 (DARK) or all brighter (BRIGHT): the one-sided half of fast_m.  A pixel cannot be a
-// dark and a bright corner at once, so where the quick test has excluded one side the other side
-// alone is the pixel's m whenever that m exceeds the threshold.
-template <int TS, bool BRIGHT>
-__device__ __forceinline__ int fast_m_side(const uint8_t* c) {
-  const int v = c[0];
+// The exact m of a pixel that the quick test left standing on one side: with s8 = 0 (bright
+// side) or 0xff (dark side) and J = I ^ s8 (dark: 255 - I),
+//   m = max(0, max over the 16 arcs of (min over the arc's 9 ring pixels of J) - (v ^ s8)).
+// A pixel cannot be a dark and a bright corner at once (nine contiguous darker ring pixels leave
+// seven others), so where one side's m is positive the other side's is zero: the side the quick
+// test queued the pixel on gives the pixel's m whenever that m is positive.
+template <int TS>
+__device__ __forceinline__ int fast_m_sel(const uint8_t* c, int s8) {
   int d[16];
   d[0] = c[3 * TS + 0];
   d[1] = c[3 * TS + 1];
@@ -365,8 +366,9 @@ __device__ __forceinline__ int fast_m_side(const uint8_t* c) {
   d[13] = c[1 * TS - 3];
   d[14] = c[2 * TS - 2];
   d[15] = c[3 * TS - 1];
+  const int v = (int)c[0] ^ s8;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) d[k] = BRIGHT ? d[k] - v : v - d[k];
+  for (int k = 0; k < 16; ++k) d[k] ^= s8;
   int lo2[16], lo4[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) lo2[k] = min(d[k], d[(k + 1) & 15]);
@@ -376,70 +378,32 @@ __device__ __forceinline__ int fast_m_side(const uint8_t* c) {
 #pragma unroll
   for (int k = 0; k < 16; ++k)   // window of 9 starting at k: [k,k+4) u [k+4,k+8) u {k+8}
     best = max(best, min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]));
-  return best;
+  return max(best - v, 0);
 }
 
-// The same with the side chosen per lane (sign = 0: bright, -1: dark): (I ^ s) - (v ^ s) is
-// I - v or v - I.  Seventeen more instructions than a one-sided loop, which pays when dark and
-// bright candidates together fill one trip of the wave.
-template <int TS>
-__device__ __forceinline__ int fast_m_signed(const uint8_t* c, int s) {
-  const int v = (int)c[0] ^ s;
-  int d[16];
-  d[0] = c[3 * TS + 0];
-  d[1] = c[3 * TS + 1];
-  d[2] = c[2 * TS + 2];
-  d[3] = c[1 * TS + 3];
-  d[4] = c[3];
-  d[5] = c[-1 * TS + 3];
-  d[6] = c[-2 * TS + 2];
-  d[7] = c[-3 * TS + 1];
-  d[8] = c[-3 * TS + 0];
-  d[9] = c[-3 * TS - 1];
-  d[10] = c[-2 * TS - 2];
-  d[11] = c[-1 * TS - 3];
-  d[12] = c[-3];
-  d[13] = c[1 * TS - 3];
-  d[14] = c[2 * TS - 2];
-  d[15] = c[3 * TS - 1];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) d[k] = (d[k] ^ s) - v;
-  int lo2[16], lo4[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) lo2[k] = min(d[k], d[(k + 1) & 15]);
-#pragma unroll
-  for (int k = 0; k < 16; ++k) lo4[k] = min(lo2[k], lo2[(k + 2) & 15]);
-  int best = 0;
-#pragma unroll
-  for (int k = 0; k < 16; ++k)
-    best = max(best, min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]));
-  return best;
-}
+// floor(65536 / n) + 1: floor(a / n) = (a * magic) >> 16 for 0 <= a <= 64, 1 <= n <= 23
+__constant__ uint32_t c_div_magic[24] = {0,    65537, 32769, 21846, 16385, 13108, 10923, 9363, 8193, 7282, 6554, 5958,
+                                         5462, 5042,  4682,  4370,  4097,  3856,  3641,  3450, 3277, 3121, 2979, 2850};
 
 // Quick corner test for the four pixels at window bytes 4..7 of window row WR, four pixels per
-// instruction on halved pixel values (7 bits in a byte, bit 7 free to catch the carry of a
-// per-byte comparison).  R = 8 window rows x 3 dwords of the halved tile.
+// instruction on pixel values cut to 6 bits (bits 6 and 7 of a byte free, so that a per-byte
+// comparison can neither carry nor borrow across bytes and needs no saturation).  R = 8 window
+// rows x 3 dwords of the 6-bit tile.
 //
-// With I7 = I >> 1, v7 = v >> 1 and c = (t + 1) >> 1: a ring pixel darker than the centre by more
-// than t has I7 <= v7 - c, a brighter one I7 >= v7 + c (necessary, not sufficient: the halving
-// loosens both by at most one grey level).  A 9-arc holds one pixel of each of the 8 opposite
+// With I6 = I >> 2, v6 = v >> 2 and c = (t + 1) >> 2: a ring pixel darker than the centre by more
+// than t has I6 <= v6 - c, a brighter one I6 >= v6 + c (necessary, not sufficient: the cut
+// loosens both by at most three grey levels).  A 9-arc holds one pixel of each of the 8 opposite
 // ring pairs, so a dark (bright) corner needs a dark (bright) pixel in every pair; the 4 axis and
-// diagonal pairs are tested.  Per byte, with nt = min(0x7f - v7 + c, 0x80) and
-// ug = 0x80 | min(v7 + c - 1, 0x7f):
-//   bit 7 of (I7 + nt) = "not dark",   bit 7 of (ug - I7) = "not bright",
-// and neither operation carries or borrows across bytes.  kD = 0x7f7f7f7f + c * 0x01010101,
-// kU = (c - 1) * 0x01010101, 1 <= c <= 0x80.  Returns in bit 7 of each byte of dark / bright
-// whether the pixel can still be a dark / bright corner.
+// diagonal pairs are tested.  Per byte, with nt = 0x7f + c - v6 and ug = 0x7f + c + v6
+// (both below 0x100 for 1 <= c <= 64):
+//   bit 7 of (I6 + nt) = "not dark",   bit 7 of (ug - I6) = "not bright".
+// k = (0x7f + c) * 0x01010101.  Returns in bit 7 of each byte of dark / bright whether the
+// pixel can still be a dark / bright corner.
 template <int WR>
-__device__ __forceinline__ void quick4(const uint32_t (&R)[8][3], uint32_t kD, uint32_t kU, uint32_t& dark,
-                                       uint32_t& bright) {
+__device__ __forceinline__ void quick4(const uint32_t (&R)[8][3], uint32_t k, uint32_t& dark, uint32_t& bright) {
   const uint32_t V = R[WR][1];
-  uint32_t nt = kD - V;
-  const uint32_t h = nt & 0x80808080u;
-  nt &= ~(h - (h >> 7));
-  const uint32_t s = V + kU;
-  const uint32_t g = s & 0x80808080u;
-  const uint32_t ug = s | (g - (g >> 7)) | 0x80808080u;
+  const uint32_t nt = k - V;
+  const uint32_t ug = k + V;
   uint32_t nd, nb;
   {   // (0,3) / (0,-3): aligned
     const uint32_t a = R[WR + 3][1], b = R[WR - 3][1];
@@ -465,134 +429,161 @@ __device__ __forceinline__ void quick4(const uint32_t (&R)[8][3], uint32_t kD, u
   bright = ~nb & 0x80808080u;
 }
 
+// The tile cut to 6 bits per pixel (quick test), one lane per tile row.
+template <int TS>
+__device__ __forceinline__ void fast_cut_tile(const uint8_t* tile, uint8_t* q6, int rows, int lane) {
+  for (int r = lane; r < rows; r += 64) {
+#pragma unroll
+    for (int n = 0; n < TS / 16; ++n) {
+      const uint4 o = *(const uint4*)(tile + r * TS + 16 * n);
+      uint4 hv;
+      hv.x = (o.x >> 2) & 0x3f3f3f3fu; hv.y = (o.y >> 2) & 0x3f3f3f3fu;
+      hv.z = (o.z >> 2) & 0x3f3f3f3fu; hv.w = (o.w >> 2) & 0x3f3f3f3fu;
+      *(uint4*)(q6 + r * TS + 16 * n) = hv;
+    }
+  }
+}
+
+// What a detection pass leaves behind for the output step.
+struct FastPass {
+  bool anyHi;      // some suppressed corner has m > thHi
+  bool perPixel;   // the pass scored every pixel (no corner list)
+  int ncorner;     // corner list: queue[0 .. ncorner) = y << 7 | x of the pixels with m > tlow
+};
+
 // One detection pass of a cell at threshold tlow (steps 2-4 of the kernel below): quick
 // rejection, exact m for the survivors, suppression.  bitsHi collects the suppressed corners
-// with m > thHi, bitsLo (may be null) those with m > thLo.  Returns whether any lane set a
-// bitsHi bit (workgroup-wide).  half = the tile with every pixel halved; qcnt = two counters.
+// with m > thHi, bitsLo (may be null) those with m > thLo.  q6 = the tile cut to 6 bits; lr, gx
+// = the lane's row and column in the grid of quick-test tasks (4 columns x 2 rows of pixels per
+// task, ngx tasks per row, rpt task rows per trip of the wave).
 template <int TS>
-__device__ __forceinline__ bool fast_pass(const uint8_t* tile, const uint8_t* half, uint8_t* mm, uint16_t* queue,
-                                          int* qcnt, int qcap, int cw, int ch, int lane, int tlow, int thHi,
-                                          uint32_t* bitsHi, int thLo, uint32_t* bitsLo) {
+__device__ __forceinline__ FastPass fast_pass(const uint8_t* tile, const uint8_t* q6, uint8_t* mm, uint16_t* queue,
+                                              int* qcnt, int qcap, int cw, int ch, int lane, int lr, int gx, int rpt,
+                                              int tlow, int thHi, uint32_t* bitsHi, int thLo, uint32_t* bitsLo) {
+  FastPass res;
   const int np = cw * ch;
-  const int ngx = (cw + 3) >> 2, nry = (ch + 1) >> 1;
-  const int ntask = ngx * nry;
-  const float rngx = 1.0f / (float)ngx;
-  const float rcw = 1.0f / (float)cw;
-  if (lane == 0) { qcnt[0] = 0; qcnt[1] = 0; }
+  const int nry = (ch + 1) >> 1;
+  const uint32_t c6 = (uint32_t)(tlow + 1) >> 2;
+  if (lane == 0) qcnt[0] = 0;
   __syncthreads();
   // ---- 2. quick rejection, 4 columns x 2 rows per lane ----------------------
-  // Survivors that can be dark corners are queued from the front of the queue, those that can be
-  // bright corners from its back (a pixel that can be either goes to both); the position comes
-  // from an LDS counter, so the order inside a queue is arbitrary - nothing below depends on it.
-  if (tlow >= 1) {
-    const uint32_t c = (uint32_t)(tlow + 1) >> 1;
-    const uint32_t kD = 0x7f7f7f7fu + c * 0x01010101u, kU = (c - 1u) * 0x01010101u;
-    for (int base = 0; base < ntask; base += 64) {
-      const int tsk = base + lane;
-      if (tsk < ntask) {
-        const int r = (int)(((float)tsk + 0.5f) * rngx);
-        const int x = (tsk - r * ngx) * 4, y = r * 2;
+  // Survivors are queued as (task row << 10 | task column << 5 | flag bit): bits 3..9 of an entry
+  // are the pixel's column, bit 2 its row inside the task, bit 0 the side (0 dark, 1 bright); a
+  // pixel that can be either is queued twice.  The position comes from an LDS counter, so the
+  // order of the queue is arbitrary - nothing below depends on it.
+  if (c6 >= 1) {
+    const uint32_t k = (0x7fu + c6) * 0x01010101u;
+    const bool laneOn = lr < rpt;
+    const uint8_t* wp = q6 + (2 * lr) * TS + 4 * gx;
+    uint32_t base = ((uint32_t)lr << 10) | ((uint32_t)gx << 5);
+    for (int r0 = 0; r0 < nry; r0 += rpt) {
+      if (laneOn && r0 + lr < nry) {
         uint32_t R[8][3];
-        const uint8_t* wp = half + y * TS + x;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const uint32_t* rp = (const uint32_t*)(wp + i * TS);
           R[i][0] = rp[0]; R[i][1] = rp[1]; R[i][2] = rp[2];
         }
         uint32_t d0, b0, d1, b1;
-        quick4<3>(R, kD, kU, d0, b0);   // row y
-        quick4<4>(R, kD, kU, d1, b1);   // row y + 1
-        // dark flags in bits 0, 8, 16, 24 (row y) and 4, 12, 20, 28 (row y + 1), bright flags one
-        // bit above them.  Pixels of the last column group / row that lie outside the cell are
-        // not masked here: the consumers of the queue skip them.
+        quick4<3>(R, k, d0, b0);   // upper row of the task
+        quick4<4>(R, k, d1, b1);   // lower row
+        // dark flags in bits 0, 8, 16, 24 (upper row) and 4, 12, 20, 28 (lower row), bright flags
+        // one bit above them.  Pixels of the last column group / row that lie outside the cell
+        // are not masked here: the consumers of the queue skip them.
         uint32_t F = (d0 >> 7) | (d1 >> 3) | (b0 >> 6) | (b1 >> 2);
         if (F) {
-          const uint32_t pos0 = (uint32_t)((y << 7) | x);
-          const unsigned long long nn = (unsigned long long)__popc(F & 0x11111111u) |
-                                        ((unsigned long long)__popc(F & 0x22222222u) << 32);
-          const unsigned long long old = atomicAdd((unsigned long long*)qcnt, nn);
-          int qd = (int)(uint32_t)old, qb = qcap - 1 - (int)(uint32_t)(old >> 32);
-          while (F) {
-            const int bit = __ffs(F) - 1;
-            F &= F - 1;
-            const int isB = bit & 1;
-            const int at = isB ? qb : qd;
-            if ((unsigned)at < (unsigned)qcap) queue[at] = (uint16_t)(pos0 + (bit >> 3) + ((bit & 4) << 5));
-            qd += 1 - isB;
-            qb -= isB;
+          const int n = __popc(F);
+          const int at = atomicAdd(qcnt, n);
+          if (at + n <= qcap) {   // else the count alone matters: the cell is scored pixel by pixel
+            uint16_t* qp = queue + at;
+            while (F) {
+              const int bit = __ffs(F) - 1;
+              F &= F - 1;
+              *qp++ = (uint16_t)(base | (uint32_t)bit);
+            }
           }
         }
       }
+      wp += 2 * rpt * TS;
+      base += (uint32_t)rpt << 10;
     }
   }
   __syncthreads();
-  // the map of m shares its LDS with the halved tile, which the quick test is done with
+  // the map of m shares its LDS with the 6-bit tile, which the quick test is done with
   {
-    const int mmq = ((ch + 2) * TS + 15) >> 4;
+    const int mmq = ((ch + 2) * TS) >> 4;
     for (int i = lane; i < mmq; i += 64) ((uint4*)mm)[i] = make_uint4(0, 0, 0, 0);
   }
   __syncthreads();
 
-  // ---- 3. exact m for the survivors -----------------------------------------
-  // (a cell with more survivors than the queue holds - noise-like content - is scored
-  // and suppressed pixel by pixel instead; so is a pass at threshold 0)
-  const int nD = qcnt[0], nB = qcnt[1];
-  const bool overflow = tlow < 1 || nD + nB > qcap;
-  const int nwork = overflow ? np : nD + nB;
-  if (overflow) {
+  const int nq = qcnt[0];
+  res.perPixel = c6 < 1 || nq > qcap;
+  res.ncorner = 0;
+  int anyHi = 0;
+  if (res.perPixel) {
+    // ---- 3'. / 4'. noise-like content (more survivors than the queue holds), or a threshold
+    // below the 6-bit test's resolution: every pixel is scored and suppressed
+    const float rcw = 1.0f / (float)cw;
     for (int qi = lane; qi < np; qi += 64) {
       const int y = (int)(((float)qi + 0.5f) * rcw), x = qi - y * cw;
       mm[(y + 1) * TS + x + 4] = (uint8_t)fast_m<TS>(tile + (y + 3) * TS + x + 4);
     }
-  } else if (nwork <= 64) {
-    // one trip for both sides; a pixel queued on both sides is written by its dark entry first
-    // and maximised by its bright entry (LDS operations of one wave complete in order)
-    const bool have = lane < nwork, isB = lane >= nD;
-    const int id = have ? queue[isB ? qcap - 1 - (lane - nD) : lane] : 0;
-    const int x = id & 127, y = id >> 7;
-    const bool inside = have && x < cw && y < ch;
-    int m = 0;
-    if (inside) m = fast_m_signed<TS>(tile + (y + 3) * TS + x + 4, isB ? 0 : -1);
-    uint8_t* q = mm + (y + 1) * TS + x + 4;
-    if (inside && !isB) *q = (uint8_t)m;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    if (inside && isB) *q = (uint8_t)max((int)*q, m);
-  } else {
-    for (int qi = lane; qi < nD; qi += 64) {
-      const int id = queue[qi], x = id & 127, y = id >> 7;
-      if (x < cw && y < ch) mm[(y + 1) * TS + x + 4] = (uint8_t)fast_m_side<TS, false>(tile + (y + 3) * TS + x + 4);
-    }
     __syncthreads();
-    for (int qi = lane; qi < nB; qi += 64) {
-      const int id = queue[qcap - 1 - qi], x = id & 127, y = id >> 7;
-      if (x < cw && y < ch) {
-        uint8_t* q = mm + (y + 1) * TS + x + 4;   // the dark side may have written this pixel
-        *q = (uint8_t)max((int)*q, fast_m_side<TS, true>(tile + (y + 3) * TS + x + 4));
+    for (int qi = lane; qi < np; qi += 64) {
+      const int y = (int)(((float)qi + 0.5f) * rcw), x = qi - y * cw;
+      const uint8_t* q = mm + (y + 1) * TS + x + 4;
+      const int m = q[0];
+      if (m > tlow) {
+        const bool isMax = m > q[-1] && m > q[1] && m > q[-TS - 1] && m > q[-TS] && m > q[-TS + 1] &&
+                           m > q[TS - 1] && m > q[TS] && m > q[TS + 1];
+        if (isMax) {
+          if (m > thHi) { atomicOr(&bitsHi[qi >> 5], 1u << (qi & 31)); anyHi = 1; }
+          if (bitsLo && m > thLo) atomicOr(&bitsLo[qi >> 5], 1u << (qi & 31));
+        }
+      }
+    }
+  } else {
+    // ---- 3. exact m for the survivors, one per lane; those with m > tlow (the corners at this
+    // threshold) are written to the map and compacted to the front of the queue (a trip reads
+    // its 64 entries before it writes, and writes no further than it has read)
+    int nc = 0;
+    for (int q0 = 0; q0 < nq; q0 += 64) {
+      const int qi = q0 + lane;
+      const bool have = qi < nq;
+      const uint32_t e = have ? (uint32_t)queue[qi] : 0u;
+      const int x = (int)((e >> 3) & 127u), y = (int)(((e >> 10) << 1) | ((e >> 2) & 1u));
+      int m = 0;
+      if (have && x < cw && y < ch) m = fast_m_sel<TS>(tile + (y + 3) * TS + x + 4, (e & 1u) ? 0 : 0xff);
+      const bool corner = m > tlow;
+      const unsigned long long mask = __ballot(corner);
+      if (corner) {
+        mm[(y + 1) * TS + x + 4] = (uint8_t)m;
+        queue[nc + mbcnt64(mask)] = (uint16_t)((y << 7) | x);
+      }
+      nc += __popcll(mask);
+    }
+    res.ncorner = nc;
+    __syncthreads();
+    // ---- 4. suppression inside the cell ---------------------------------------
+    for (int q0 = 0; q0 < nc; q0 += 64) {
+      const int qi = q0 + lane;
+      if (qi < nc) {
+        const int id = queue[qi], x = id & 127, y = id >> 7;
+        const uint8_t* q = mm + (y + 1) * TS + x + 4;
+        const int m = q[0];
+        const bool isMax = m > q[-1] && m > q[1] && m > q[-TS - 1] && m > q[-TS] && m > q[-TS + 1] &&
+                           m > q[TS - 1] && m > q[TS] && m > q[TS + 1];
+        if (isMax) {
+          const int p = y * cw + x;
+          if (m > thHi) { atomicOr(&bitsHi[p >> 5], 1u << (p & 31)); anyHi = 1; }
+          if (bitsLo && m > thLo) atomicOr(&bitsLo[p >> 5], 1u << (p & 31));
+        }
       }
     }
   }
+  res.anyHi = __ballot(anyHi) != 0ull;
   __syncthreads();
-
-  // ---- 4. suppression inside the cell ---------------------------------------
-  int anyHi = 0;
-  for (int qi = lane; qi < nwork; qi += 64) {
-    int x, y;
-    if (overflow) { y = (int)(((float)qi + 0.5f) * rcw); x = qi - y * cw; }
-    else { const int id = queue[qi < nD ? qi : qcap - 1 - (qi - nD)]; x = id & 127; y = id >> 7; }
-    const uint8_t* q = mm + (y + 1) * TS + x + 4;
-    const int m = (x < cw && y < ch) ? q[0] : 0;   // queue entries outside the cell score nothing
-    if (m > tlow) {
-      const bool isMax = m > q[-1] && m > q[1] && m > q[-TS - 1] && m > q[-TS] && m > q[-TS + 1] &&
-                         m > q[TS - 1] && m > q[TS] && m > q[TS + 1];
-      if (isMax) {
-        const int p = y * cw + x;
-        if (m > thHi) { atomicOr(&bitsHi[p >> 5], 1u << (p & 31)); anyHi = 1; }
-        if (bitsLo && m > thLo) atomicOr(&bitsLo[p >> 5], 1u << (p & 31));
-      }
-    }
-  }
-  return __syncthreads_or(anyHi) != 0;
+  return res;
 }
 
 template <int TS>
@@ -620,93 +611,127 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Plan* __restrict__ plan
   const int nwords = (np + 31) >> 5;
 
   uint8_t* tile = smem;                                   // fast_tile_rows x TS
-  uint8_t* half = tile + plan->fast_tile_rows * TS;       // the same pixels, halved (quick test)
-  uint8_t* mm = half;                                     // fast_mm_rows x TS, once the quick test is done
-  uint16_t* queue = (uint16_t*)(half + plan->fast_tile_rows * TS);
+  uint8_t* q6 = tile + plan->fast_tile_rows * TS;         // the same pixels cut to 6 bits (quick test)
+  uint8_t* mm = q6;                                       // fast_mm_rows x TS, once the quick test is done
+  uint16_t* queue = (uint16_t*)(q6 + plan->fast_tile_rows * TS);
   uint32_t* bitsIni = (uint32_t*)(queue + plan->fast_qcap);
   uint32_t* bitsMin = bitsIni + plan->fast_words;
-  int* qcnt = (int*)(((uintptr_t)(bitsMin + plan->fast_words) + 7) & ~(uintptr_t)7);   // one 8-byte counter pair
+  uint16_t* prefix = (uint16_t*)(bitsMin + plan->fast_words);          // corners before each mask word
+  int* qcnt = (int*)(((uintptr_t)(prefix + plan->fast_words) + 3) & ~(uintptr_t)3);
 
   // ---- 1. tile: LDS (row r, col c) = level pixel (X0 - 4 + c, Y0 - 3 + r) ----
   {
     const int shift = (X0 + 15) & 3;  // planes and rows are 64-byte aligned
     const uint8_t* g0 = pyr + L.pyr_off + (size_t)f * L.pyr_plane +
                         (size_t)(Y0 - 3 + ORBX_EDGE) * L.pstride + (X0 - 4 + ORBX_EDGE - shift);
-    // one lane = 16 bytes of a tile row: a dword-aligned 16-byte load plus the next dword,
-    // shifted into place with v_alignbyte, one 16-byte LDS store
-    const int nq = TS / 16;
-    const int total = (ch + 6) * nq;
-    for (int i = lane; i < total; i += 64) {
-      const int r = i / nq, n = i - r * nq;
-      const uint8_t* gp = g0 + (size_t)r * L.pstride + 16 * n;
-      const U4A4 v = *(const U4A4*)gp;
-      const uint32_t v4 = *(const uint32_t*)(gp + 16);
-      uint4 o;
-      o.x = __builtin_amdgcn_alignbyte(v.y, v.x, shift);
-      o.y = __builtin_amdgcn_alignbyte(v.z, v.y, shift);
-      o.z = __builtin_amdgcn_alignbyte(v.w, v.z, shift);
-      o.w = __builtin_amdgcn_alignbyte(v4, v.w, shift);
-      *(uint4*)(tile + r * TS + 16 * n) = o;
-      uint4 hv;
-      hv.x = (o.x >> 1) & 0x7f7f7f7fu; hv.y = (o.y >> 1) & 0x7f7f7f7fu;
-      hv.z = (o.z >> 1) & 0x7f7f7f7fu; hv.w = (o.w >> 1) & 0x7f7f7f7fu;
-      *(uint4*)(half + r * TS + 16 * n) = hv;
+    // one lane = one tile row: dword-aligned 16-byte loads plus one more dword, shifted into
+    // place with v_alignbyte, 16-byte LDS stores of the pixels and of their 6-bit cut
+    for (int r = lane; r < ch + 6; r += 64) {
+      const uint8_t* gp = g0 + (size_t)r * L.pstride;
+      U4A4 v[TS / 16];
+#pragma unroll
+      for (int n = 0; n < TS / 16; ++n) v[n] = *(const U4A4*)(gp + 16 * n);
+      const uint32_t vlast = *(const uint32_t*)(gp + TS);
+#pragma unroll
+      for (int n = 0; n < TS / 16; ++n) {
+        const uint32_t nx = n + 1 < TS / 16 ? v[n + 1 < TS / 16 ? n + 1 : n].x : vlast;
+        uint4 o;
+        o.x = __builtin_amdgcn_alignbyte(v[n].y, v[n].x, shift);
+        o.y = __builtin_amdgcn_alignbyte(v[n].z, v[n].y, shift);
+        o.z = __builtin_amdgcn_alignbyte(v[n].w, v[n].z, shift);
+        o.w = __builtin_amdgcn_alignbyte(nx, v[n].w, shift);
+        *(uint4*)(tile + r * TS + 16 * n) = o;
+        uint4 hv;
+        hv.x = (o.x >> 2) & 0x3f3f3f3fu; hv.y = (o.y >> 2) & 0x3f3f3f3fu;
+        hv.z = (o.z >> 2) & 0x3f3f3f3fu; hv.w = (o.w >> 2) & 0x3f3f3f3fu;
+        *(uint4*)(q6 + r * TS + 16 * n) = hv;
+      }
     }
     for (int i = lane; i < nwords; i += 64) { bitsIni[i] = 0; bitsMin[i] = 0; }
   }
   __syncthreads();
 
+  // quick-test task grid: ngx tasks of 4 columns per row of tasks, rpt rows of tasks per trip
+  const int ngx = (cw + 3) >> 2;
+  const uint32_t magic = c_div_magic[ngx];
+  const int rpt = (int)((64u * magic) >> 16);
+  const int lr = (int)(((uint32_t)lane * magic) >> 16), gx = lane - lr * ngx;
+
   // ---- 2.-4. detection at iniThFAST, and only in a cell that yields nothing there again at
   // minThFAST (extractor.cc:789-807).  Survivors of the quick test are the pixels whose bound
   // on m exceeds the threshold of the pass, so the first pass queues (and scores exactly) far
   // fewer pixels than one pass at the lower threshold would; the few cells that need the
-  // second pass repeat the quick test.  Scores written by the first pass stay valid.
+  // second pass repeat the quick test.
   // When iniThFAST <= minThFAST (or the plan asks for it) one pass at the lower threshold serves
   // both.
   const int ini = plan->ini_th, mn = plan->min_th;
   const int qcap = plan->fast_qcap;
-  const float rcw = 1.0f / (float)cw;
+  FastPass ps;
   bool useIni;
   if (ini > mn && plan->fast_two_pass) {
-    useIni = fast_pass<TS>(tile, half, mm, queue, qcnt, qcap, cw, ch, lane, ini, ini, bitsIni, 0, nullptr);
+    ps = fast_pass<TS>(tile, q6, mm, queue, qcnt, qcap, cw, ch, lane, lr, gx, rpt, ini, ini, bitsIni, 0, nullptr);
+    useIni = ps.anyHi;
     if (!useIni) {
-      // the first pass's map of m lies where the halved tile was: make that again (the second
+      // the first pass's map of m lies where the 6-bit tile was: make that again (the second
       // pass clears the map and writes every score it needs afresh)
-      const int nq4 = (ch + 6) * (TS / 16);
-      for (int i = lane; i < nq4; i += 64) {
-        const uint4 o = ((const uint4*)tile)[i];
-        uint4 hv;
-        hv.x = (o.x >> 1) & 0x7f7f7f7fu; hv.y = (o.y >> 1) & 0x7f7f7f7fu;
-        hv.z = (o.z >> 1) & 0x7f7f7f7fu; hv.w = (o.w >> 1) & 0x7f7f7f7fu;
-        ((uint4*)half)[i] = hv;
-      }
-      (void)fast_pass<TS>(tile, half, mm, queue, qcnt, qcap, cw, ch, lane, mn, mn, bitsMin, 0, nullptr);
+      fast_cut_tile<TS>(tile, q6, ch + 6, lane);
+      ps = fast_pass<TS>(tile, q6, mm, queue, qcnt, qcap, cw, ch, lane, lr, gx, rpt, mn, mn, bitsMin, 0, nullptr);
     }
   } else {
-    useIni = fast_pass<TS>(tile, half, mm, queue, qcnt, qcap, cw, ch, lane, min(ini, mn), ini, bitsIni, mn, bitsMin);
+    ps = fast_pass<TS>(tile, q6, mm, queue, qcnt, qcap, cw, ch, lane, lr, gx, rpt, min(ini, mn), ini, bitsIni, mn, bitsMin);
+    useIni = ps.anyHi;
   }
   const uint32_t* bits = useIni ? bitsIni : bitsMin;
 
-  // ---- 5. ordered output ---------------------------------------------------------
+  // ---- 5. ordered output: the corners of the chosen mask in raster order -----------
   uint32_t* out = cand + (size_t)f * plan->cand_frame + L.cand_off + (size_t)cell * L.cand_cap_cell;
   int running = 0;
-  for (int wbase = 0; wbase < nwords; wbase += 64) {
-    const int wi = wbase + lane;
-    uint32_t word = wi < nwords ? bits[wi] : 0u;
-    const int c = __popc(word);
-    const int inc = wave_incl_scan(c);
-    int o = running + inc - c;
-    while (word) {
-      const int b = __ffs(word) - 1;
-      word &= word - 1;
-      const int p = wi * 32 + b;
-      const int y = (int)(((float)p + 0.5f) * rcw);
-      const int x = p - y * cw;
-      const int m = mm[(y + 1) * TS + x + 4];
-      out[o++] = (uint32_t)(X0 + x - ORBX_DET_ORG) | ((uint32_t)(Y0 + y - ORBX_DET_ORG) << 12) |
-                 ((uint32_t)(m - 1) << 24);
+  if (!ps.perPixel) {
+    // a corner's place = mask bits before it: those of the earlier words (scan) + those below
+    // it in its own word
+    for (int wbase = 0; wbase < nwords; wbase += 64) {
+      const int wi = wbase + lane;
+      const uint32_t word = wi < nwords ? bits[wi] : 0u;
+      const int c = __popc(word);
+      const int inc = wave_incl_scan(c);
+      if (wi < nwords) prefix[wi] = (uint16_t)(running + inc - c);
+      running += __shfl(inc, 63, 64);
     }
-    running += __shfl(inc, 63, 64);
+    __syncthreads();
+    for (int q0 = 0; q0 < ps.ncorner; q0 += 64) {
+      const int qi = q0 + lane;
+      if (qi < ps.ncorner) {
+        const int id = queue[qi], x = id & 127, y = id >> 7;
+        const int p = y * cw + x;
+        const uint32_t word = bits[p >> 5], bit = 1u << (p & 31);
+        if (word & bit) {
+          const int o = (int)prefix[p >> 5] + __popc(word & (bit - 1u));
+          const int m = mm[(y + 1) * TS + x + 4];
+          out[o] = (uint32_t)(X0 + x - ORBX_DET_ORG) | ((uint32_t)(Y0 + y - ORBX_DET_ORG) << 12) |
+                   ((uint32_t)(m - 1) << 24);
+        }
+      }
+    }
+  } else {
+    const float rcw = 1.0f / (float)cw;
+    for (int wbase = 0; wbase < nwords; wbase += 64) {
+      const int wi = wbase + lane;
+      uint32_t word = wi < nwords ? bits[wi] : 0u;
+      const int c = __popc(word);
+      const int inc = wave_incl_scan(c);
+      int o = running + inc - c;
+      while (word) {
+        const int b = __ffs(word) - 1;
+        word &= word - 1;
+        const int p = wi * 32 + b;
+        const int y = (int)(((float)p + 0.5f) * rcw);
+        const int x = p - y * cw;
+        const int m = mm[(y + 1) * TS + x + 4];
+        out[o++] = (uint32_t)(X0 + x - ORBX_DET_ORG) | ((uint32_t)(Y0 + y - ORBX_DET_ORG) << 12) |
+                   ((uint32_t)(m - 1) << 24);
+      }
+      running += __shfl(inc, 63, 64);
+    }
   }
   if (lane == 0) cellCount[(size_t)f * plan->cells_per_frame + cellg] = running;
 }
@@ -1763,8 +1788,9 @@ void launch_pyramid(const Plan& hp, const uint8_t* d_img, int istride, size_t if
 }
 
 size_t fast_lds_bytes(const Plan& hp, int ts) {
-  // tile + halved tile (the map of m reuses the latter: fast_mm_rows <= fast_tile_rows) + queue + masks
-  return (size_t)(2 * hp.fast_tile_rows) * ts + (size_t)hp.fast_qcap * 2 + (size_t)hp.fast_words * 8 + 8 + 16;
+  // tile + 6-bit tile (the map of m reuses the latter: fast_mm_rows <= fast_tile_rows) + queue + two masks +
+  // per-word corner counts + the queue counter
+  return (size_t)(2 * hp.fast_tile_rows) * ts + (size_t)hp.fast_qcap * 2 + (size_t)hp.fast_words * 10 + 8 + 16;
 }
 
 // cells of levels [l0, l1)

@@ -89,7 +89,8 @@ def test_shard_bounds_cover_everything_once():
 def test_launch_block_sizes_match_launch_bounds():
     """A launch with more threads than the kernel's __launch_bounds__ fails on the device and
     nowhere else (the host simulation does not know the bounds): every hipLaunchKernelGGL in the
-    library names the same block size as the kernel's declaration."""
+    library names the block size of the kernel's declaration, or a smaller literal one (a kernel
+    that also runs as narrower workgroups: the bounds are a maximum)."""
     import glob
     import re
     src = "".join(open(f).read() for f in sorted(glob.glob(os.path.join(ROOT, "orb_slam3_amd", "csrc", "*.hip"))))
@@ -106,7 +107,10 @@ def test_launch_block_sizes_match_launch_bounds():
         if kernel in by_variable:
             continue
         assert kernel in bounds, kernel
-        assert block == bounds[kernel], (kernel, block, bounds[kernel])
+        if block.isdigit() and bounds[kernel].isdigit():
+            assert int(block) % 64 == 0 and int(block) <= int(bounds[kernel]), (kernel, block, bounds[kernel])
+        else:
+            assert block == bounds[kernel], (kernel, block, bounds[kernel])
     assert seen >= 30
 
 

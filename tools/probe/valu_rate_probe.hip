@@ -48,6 +48,29 @@ DEFINE_KERNEL(k_mulf, "v_mul_f32 %0, %0, %1")
 DEFINE_KERNEL(k_cvt, "v_cvt_f32_u32 %0, %0")
 DEFINE_KERNEL(k_bfe, "v_bfe_u32 %0, %0, 3, 8")
 DEFINE_KERNEL(k_madi64, "v_mad_u32_u16 %0, %0, %1, %2")
+DEFINE_KERNEL(k_andor, "v_and_or_b32 %0, %0, %1, %2")
+DEFINE_KERNEL(k_or3, "v_or3_b32 %0, %0, %1, %2")
+DEFINE_KERNEL(k_sub, "v_sub_u32 %0, %1, %0")
+DEFINE_KERNEL(k_alignbit, "v_alignbit_b32 %0, %0, %1, 31")
+DEFINE_KERNEL(k_maxu, "v_max_u32 %0, %0, %1")
+DEFINE_KERNEL(k_ffbl, "v_ffbl_b32 %0, %0")
+DEFINE_KERNEL(k_bfi, "v_bfi_b32 %0, %1, %0, %2")
+DEFINE_KERNEL(k_max3, "v_max3_i32 %0, %0, %1, %2")
+DEFINE_KERNEL(k_addlit, "v_add_u32 %0, 0x7f7f7f89, %0")
+DEFINE_KERNEL(k_andlit, "v_and_b32 %0, 0x80808080, %0")
+DEFINE_KERNEL(k_med3, "v_med3_i32 %0, %0, %1, %2")
+DEFINE_KERNEL(k_xad, "v_xad_u32 %0, %0, %1, %2")
+DEFINE_KERNEL(k_lshladd, "v_lshl_add_u32 %0, %0, 1, %1")
+DEFINE_KERNEL(k_addlshl, "v_add_lshl_u32 %0, %0, %1, 1")
+DEFINE_KERNEL(k_mbcnt, "v_mbcnt_lo_u32_b32 %0, %1, %0")
+DEFINE_KERNEL(k_not, "v_not_b32 %0, %0")
+DEFINE_KERNEL(k_or, "v_or_b32 %0, %0, %1")
+DEFINE_KERNEL(k_mov, "v_mov_b32 %0, %1")
+DEFINE_KERNEL(k_cmpcnd, "v_cmp_lt_u32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %2, vcc")
+DEFINE_KERNEL(k_sdwa, "v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD")
+DEFINE_KERNEL(k_dpp, "v_add_u32_dpp %0, %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+DEFINE_KERNEL(k_pkmaxi, "v_pk_max_i16 %0, %0, %1")
+DEFINE_KERNEL(k_pklshl, "v_pk_lshlrev_b16 %0, 1, %0")
 
 struct Entry { const char* name; void (*fn)(uint32_t*, uint32_t); };
 
@@ -64,7 +87,13 @@ int main() {
                 {"v_xor_b32", k_xor}, {"v_and_b32", k_and}, {"v_lshrrev_b32", k_lshr},
                 {"v_cndmask_b32", k_cndmask}, {"v_min_i32", k_min}, {"v_fma_f32", k_fma},
                 {"v_mul_f32", k_mulf}, {"v_cvt_f32_u32", k_cvt}, {"v_bfe_u32", k_bfe},
-                {"v_mad_u32_u16", k_madi64}};
+                {"v_mad_u32_u16", k_madi64}, {"v_and_or_b32", k_andor}, {"v_or3_b32", k_or3}, {"v_sub_u32", k_sub},
+                {"v_alignbit_b32", k_alignbit}, {"v_max_u32", k_maxu}, {"v_ffbl_b32", k_ffbl}, {"v_bfi_b32", k_bfi},
+                {"v_max3_i32", k_max3}, {"v_add_u32 literal", k_addlit}, {"v_and_b32 literal", k_andlit},
+                {"v_med3_i32", k_med3}, {"v_xad_u32", k_xad}, {"v_lshl_add_u32", k_lshladd},
+                {"v_add_lshl_u32", k_addlshl}, {"v_mbcnt_lo", k_mbcnt}, {"v_not_b32", k_not}, {"v_or_b32", k_or},
+                {"v_mov_b32", k_mov}, {"v_cmp + v_cndmask (pair)", k_cmpcnd}, {"v_add_u32 sdwa", k_sdwa},
+                {"v_add_u32 dpp", k_dpp}, {"v_pk_max_i16", k_pkmaxi}, {"v_pk_lshlrev_b16", k_pklshl}};
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   double base = 0;
