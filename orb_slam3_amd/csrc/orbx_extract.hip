@@ -160,14 +160,20 @@ struct ResizeRows {
   uint32_t wy0[4], wy1[4];     // vertical weights << 12
 };
 
+// Source rows of 4 destination rows.  prev = the row tap before tys[0] (null for the first
+// step): a destination row whose upper source row is the previous destination row's lower one
+// takes that row's horizontal sums over, so its upper row is not loaded (wave-uniform test).
 __device__ __forceinline__ void resize_fetch(ResizeRows& R, const uint8_t* base, int sstride,
-                                             const Tap* tys) {
+                                             const Tap* tys, const Tap* prev) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     // one 12-byte load per source row (dword-aligned)
-    const U3A4 a = *(const U3A4*)(base + (size_t)tys[r].s0 * sstride);
+    const Tap* before = r > 0 ? tys + r - 1 : prev;
+    if (!(before && before->s1 == tys[r].s0)) {
+      const U3A4 a = *(const U3A4*)(base + (size_t)tys[r].s0 * sstride);
+      R.a[r][0] = a.x; R.a[r][1] = a.y; R.a[r][2] = a.z;
+    }
     const U3A4 b = *(const U3A4*)(base + (size_t)tys[r].s1 * sstride);
-    R.a[r][0] = a.x; R.a[r][1] = a.y; R.a[r][2] = a.z;
     R.b[r][0] = b.x; R.b[r][1] = b.y; R.b[r][2] = b.z;
     // (b * (H >> 4)) >> 16 is the high word of the 24-bit product (b << 12) * (H & ~15)
     R.wy0[r] = (uint32_t)(int)tys[r].w0 << 12;
@@ -244,27 +250,38 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const uint8_t* __restrict__ 
 #pragma unroll
   for (int r = 0; r < rowsPerWave; ++r) tys[r] = ytab[min(pyBase + r, prows - 1)];
   ResizeRows buf[2];
-  resize_fetch(buf[0], base, sstride, tys);
+  resize_fetch(buf[0], base, sstride, tys, nullptr);
+  uint32_t hprev[4] = {0u, 0u, 0u, 0u};   // horizontal sums (low 4 bits cleared) of the previous row's lower source row
 #pragma unroll
   for (int g = 0; g < GROUPS; ++g) {
     const int py0 = pyBase + 4 * g;
     if (py0 >= prows) break;
-    if (g + 1 < GROUPS) resize_fetch(buf[(g + 1) & 1], base, sstride, tys + 4 * (g + 1));
+    if (g + 1 < GROUPS) resize_fetch(buf[(g + 1) & 1], base, sstride, tys + 4 * (g + 1), tys + 4 * g + 3);
     const ResizeRows& cur = buf[g & 1];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int py = py0 + r;
       if (py < prows) {
-        const uint32_t alo = __builtin_amdgcn_alignbyte(cur.a[r][1], cur.a[r][0], sh), ahi = __builtin_amdgcn_alignbyte(cur.a[r][2], cur.a[r][1], sh);
+        const int rg = 4 * g + r;
+        const bool shared = rg > 0 && tys[rg - 1].s1 == tys[rg].s0;   // wave-uniform
         const uint32_t blo = __builtin_amdgcn_alignbyte(cur.b[r][1], cur.b[r][0], sh), bhi = __builtin_amdgcn_alignbyte(cur.b[r][2], cur.b[r][1], sh);
+        uint32_t h0[4], h1[4];
+        // horizontal: S[sx]*a0 + S[sx+1]*a1 (<= 255*2048 < 2^20)
+        if (shared) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) h0[k] = hprev[k];
+        } else {
+          const uint32_t alo = __builtin_amdgcn_alignbyte(cur.a[r][1], cur.a[r][0], sh), ahi = __builtin_amdgcn_alignbyte(cur.a[r][2], cur.a[r][1], sh);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) h0[k] = udot2(__builtin_amdgcn_perm(ahi, alo, sel[k]), wp[k], 0u) & 0xFFFFF0u;
+        }
         uint32_t v[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          // horizontal: S[sx]*a0 + S[sx+1]*a1 (<= 255*2048 < 2^20); vertical: the 8-bit
-          // specialisation's ((b*(H>>4))>>16 + ... + 2) >> 2 (<= 255)
-          const uint32_t h0 = udot2(__builtin_amdgcn_perm(ahi, alo, sel[k]), wp[k], 0u);
-          const uint32_t h1 = udot2(__builtin_amdgcn_perm(bhi, blo, sel[k]), wp[k], 0u);
-          v[k] = (mul_hi_u24(cur.wy0[r], h0 & 0xFFFFF0u) + mul_hi_u24(cur.wy1[r], h1 & 0xFFFFF0u) + 2u) >> 2;
+          h1[k] = udot2(__builtin_amdgcn_perm(bhi, blo, sel[k]), wp[k], 0u) & 0xFFFFF0u;
+          // vertical: the 8-bit specialisation's ((b*(H>>4))>>16 + ... + 2) >> 2 (<= 255)
+          v[k] = (mul_hi_u24(cur.wy0[r], h0[k]) + mul_hi_u24(cur.wy1[r], h1[k]) + 2u) >> 2;
+          hprev[k] = h1[k];
         }
         *(uint32_t*)(dcol + (size_t)py * pstride) = (v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24)) & keep;
       }
