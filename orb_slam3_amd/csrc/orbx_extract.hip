@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const uint8_t* __restrict__ 
 
 // ---------------------------------------------------------------------------
 // K2: per-cell FAST-9/16 + non-max suppression + two-threshold retry +
-// ordered compaction.  One 256-thread workgroup per grid cell.
+// ordered compaction.  One wave (a 64-thread workgroup) per grid cell.
 //
 // For a pixel with centre v and ring pixels I_k let
 //   m = max over the 16 contiguous 9-arcs and both signs of min_arc (+-(v - I_k)).
@@ -302,18 +302,21 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const uint8_t* __restrict__ 
 // detection domain; domains tile [19, w-19) x [19, h-19) without overlap.
 // ---------------------------------------------------------------------------
 // Implementation: one wave per cell.
-//   1. the cell's pixels plus a 3-pixel ring halo go to LDS (aligned dword
-//      loads, re-based with v_alignbyte so that cell column 0 sits at LDS
-//      column 4 and a lane's 4-pixel group is dword-aligned);
-//   2. quick rejection for every pixel, 8 pixels (4 columns x 2 rows) per lane
-//      and two pixels per instruction (packed 16-bit min/max): a 9-arc holds
-//      one pixel of each of the 8 opposite ring pairs, so a corner needs
-//      max_k min(I_k, I_k+8) < v - t  or  min_k max(I_k, I_k+8) > v + t
-//      (evaluated over the 4 axis/diagonal pairs);
-//      survivors (a few percent of the pixels) are queued in LDS;
-//   3. the exact m for queued pixels only, one pixel per lane;
-//   4. suppression + threshold choice + ordered output through bit masks in
-//      raster order.
+//   1. the cell's pixels plus a 3-pixel ring halo go to LDS, one lane per tile
+//      row (dword-aligned 16-byte loads, re-based with v_alignbyte so that cell
+//      column 0 sits at LDS column 4 and a 4-pixel group is dword-aligned),
+//      together with a copy cut to 6 bits per pixel;
+//   2. quick rejection for every pixel on the 6-bit copy, 8 pixels (4 columns
+//      x 2 rows) per lane and four pixels per instruction: a 9-arc holds one
+//      pixel of each of the 8 opposite ring pairs, so a dark (bright) corner
+//      needs a dark (bright) pixel in each of the 4 axis / diagonal pairs;
+//      survivors (a few percent of the pixels) are queued in LDS with their side;
+//   3. the exact one-sided m of the queued pixels, one per lane; those above
+//      the threshold are written to the map of m and kept as the corner list;
+//   4. suppression over the corner list, corners into bit masks in raster order;
+//   5. output: a corner's place is the number of mask bits before it.
+// A cell with more survivors than the queue holds (noise), or a threshold
+// below the 6-bit test's resolution, is scored and suppressed pixel by pixel.
 // TS = LDS row stride in bytes of the tile and of the m map (cell width <= TS - 8).
 template <int TS>
 __device__ __forceinline__ int fast_m(const uint8_t* c) {

@@ -23,6 +23,14 @@ def binary_noise(w, h, seed=4):
     return np.where(rng.random((h, w)) < 0.5, 100, 119).astype(np.uint8)
 
 
+def dot_grid(w, h, step):
+    """Single bright pixels every `step` pixels: every dot is an isolated corner, about
+    (cell side / step)^2 of them per cell - more than one trip of the wave for step 4."""
+    img = np.full((h, w), 50, np.uint8)
+    img[::step, ::step] = 200
+    return img
+
+
 def mixed(w, h):
     """Left third: strong texture; middle: faint noise (only the second pass fires); right: flat."""
     img = np.full((h, w), 90, np.uint8)
@@ -38,6 +46,12 @@ def mixed(w, h):
     ("faint binary noise, 51-pixel cells", binary_noise(134, 134), (300, 1.2, 1, 20, 7)),
     ("faint binary noise, two levels", binary_noise(171, 140), (300, 1.2, 2, 20, 7)),
     ("mixed", mixed(752, 480), (1000, 1.2, 8, 20, 7)),
+    ("faint noise 4, minimum threshold below the quick test's resolution", low_contrast_noise(200, 160, 4), (300, 1.2, 2, 20, 2)),
+    ("both thresholds below the quick test's resolution", orbx.textured_frame(9, 200, 160), (300, 1.2, 2, 2, 1)),
+    ("one 69-pixel cell per row (widest tile)", orbx.textured_frame(10, 101, 101), (60, 1.2, 1, 20, 7)),
+    ("69-pixel cells, noise", low_contrast_noise(101, 170, 60, seed=11), (200, 1.2, 1, 20, 7)),
+    ("dense corners: more than 64 per cell", dot_grid(240, 200, 4), (4000, 1.2, 2, 30, 12)),
+    ("dense noise corners", low_contrast_noise(240, 200, 160, seed=12), (2000, 1.2, 2, 40, 12)),
     ("equal thresholds", orbx.textured_frame(8, 376, 240), (400, 1.2, 4, 15, 15)),
     ("ini below min", orbx.textured_frame(8, 376, 240), (400, 1.2, 4, 10, 25)),
 ], ids=lambda v: v if isinstance(v, str) else None)
@@ -54,6 +68,6 @@ def test_detection_paths_match_oracle(oracle, name, img, params):
         assert np.array_equal(k[fld], rk[fld]), fld
     if len(rk):
         assert np.array_equal(d, rd)
-    if "faint" in name:
+    if "faint" in name and "resolution" not in name:
         # nothing reaches iniThFAST, so every candidate comes from the second pass
         assert len(rk) > 50 and rk["response"].max() < params[3]
