@@ -14,6 +14,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -120,6 +121,149 @@ __global__ __launch_bounds__(KNN_BLOCK) void k_knn2(const uint32_t* __restrict__
       out_idx[o + 1] = k1[u] == 0xFFFFFFFFu ? 0xFFFFFFFFu : base + (k1[u] & mask);
       out_dist[o] = k0[u] == 0xFFFFFFFFu ? (uint16_t)0xFFFF : (uint16_t)(k0[u] >> KNN_IDX_BITS);
       out_dist[o + 1] = k1[u] == 0xFFFFFFFFu ? (uint16_t)0xFFFF : (uint16_t)(k1[u] >> KNN_IDX_BITS);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// The same scan on the matrix cores.  With every descriptor bit b written as the
+// signed byte 1 - 2 b, the dot product of two descriptors over their 256 bits is
+// 256 - 2 * (Hamming distance): an all-pairs search is a 256-deep int8 matrix
+// product, which v_mfma_i32_32x32x32_i8 computes at about four times the rate the
+// vector ALU reaches with xor + popcount.
+//
+// A workgroup of four waves owns KM_QPB queries for one train segment.  A wave
+// keeps KM_NQT tiles of 32 queries as the B operand in registers for the whole
+// scan (lane l: query l & 31, bits 16 (l >> 5) .. + 15 of every 32-bit word, one
+// byte per bit).  Train rows come in tiles of 32: the workgroup reads a tile's
+// packed bits (1 KB), writes them to LDS as signed bytes in the order the A
+// operand wants them (k-step, half, row: a wave's 16-byte reads are contiguous),
+// double-buffered, and every wave multiplies the tile with its query tiles.  In
+// the 32 x 32 result a lane holds one query's products with 16 of the tile's rows
+// (row = (i & 3) + 8 (i >> 2) + 4 (l >> 5) for register i), ascending, so the top-2
+// upkeep is per lane: one compare per pair decides whether a row can enter (its
+// distance is below the lane's current second-best; rows arrive in ascending
+// index, so a tie loses), and the key arithmetic runs only in the steps where
+// some lane has such a row.  The two lanes of a query merge their pairs at the end.
+// Any slot order of the 32 k values inside an instruction would do, as long as A
+// and B use the same one: a dot product does not care.
+// ---------------------------------------------------------------------------
+#define KM_NQT 2                              // query tiles of 32 per wave
+#define KM_WAVES 4
+#define KM_QPB (KM_WAVES * KM_NQT * 32)       // queries per workgroup
+typedef int km_v4i __attribute__((ext_vector_type(4)));
+typedef int km_v16i __attribute__((ext_vector_type(16)));
+
+// 4 bits -> 4 bytes: +1 for a clear bit, -1 for a set one
+__device__ __forceinline__ uint32_t pm1_bytes(uint32_t nib) {
+  const uint32_t t = (nib * 0x00204081u) & 0x01010101u;   // bit i -> bit 0 of byte i
+  return (t * 0xFEu) | 0x01010101u;
+}
+__device__ __forceinline__ km_v4i pm1_expand16(uint32_t bits) {
+  km_v4i r;
+  r.x = (int)pm1_bytes(bits & 15u);
+  r.y = (int)pm1_bytes((bits >> 4) & 15u);
+  r.z = (int)pm1_bytes((bits >> 8) & 15u);
+  r.w = (int)pm1_bytes((bits >> 12) & 15u);
+  return r;
+}
+
+__global__ __launch_bounds__(256) void k_knn2_mfma(const uint32_t* __restrict__ q, int nq,
+                                                   const uint32_t* __restrict__ t, long long nt,
+                                                   int seg_len, uint32_t index_offset,
+                                                   uint32_t* __restrict__ out_idx,
+                                                   uint16_t* __restrict__ out_dist) {
+  __shared__ __align__(16) uint8_t sA[2][8192];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int seg = blockIdx.y;
+  const long long t0 = (long long)seg * seg_len;
+  const int len = (int)min((long long)seg_len, nt - t0);
+  // ---- the wave's queries as B operands --------------------------------------
+  km_v4i bq[KM_NQT][8];
+#pragma unroll
+  for (int qt = 0; qt < KM_NQT; ++qt) {
+    const int qi = blockIdx.x * KM_QPB + (wave * KM_NQT + qt) * 32 + r;
+    const uint4* qp = (const uint4*)(q + (size_t)min(qi, nq - 1) * 8);
+    const uint4 a = qp[0], b = qp[1];
+    const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int s = 0; s < 8; ++s) bq[qt][s] = pm1_expand16((w[s] >> (16 * h)) & 0xFFFFu);
+  }
+  uint32_t k0[KM_NQT], k1[KM_NQT];
+  int thd[KM_NQT];   // a row can enter when its product exceeds this (256 - 2 * second-best distance)
+#pragma unroll
+  for (int qt = 0; qt < KM_NQT; ++qt) { k0[qt] = 0xFFFFFFFFu; k1[qt] = 0xFFFFFFFFu; thd[qt] = -257; }
+
+  // ---- train tiles -------------------------------------------------------------
+  const uint32_t* tp = t + (size_t)t0 * 8;
+  const int srow = tid >> 3, sw = tid & 7;   // staging: this thread's row of the tile and word of the row
+  const int ntiles = (len + 31) >> 5;
+  auto fetch = [&](int tile) -> uint32_t {
+    const int row = tile * 32 + srow;
+    return row < len ? tp[(size_t)row * 8 + sw] : 0u;
+  };
+  auto stage = [&](int buf, uint32_t bits) {
+    *(km_v4i*)&sA[buf][((sw * 2 + 0) * 32 + srow) * 16] = pm1_expand16(bits & 0xFFFFu);
+    *(km_v4i*)&sA[buf][((sw * 2 + 1) * 32 + srow) * 16] = pm1_expand16(bits >> 16);
+  };
+  uint32_t pre = ntiles > 0 ? fetch(0) : 0u;
+  if (ntiles > 0) stage(0, pre);
+  __syncthreads();
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const int cur = tile & 1;
+    if (tile + 1 < ntiles) pre = fetch(tile + 1);
+    km_v16i acc[KM_NQT];
+#pragma unroll
+    for (int qt = 0; qt < KM_NQT; ++qt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[qt][i] = 0;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const km_v4i a = *(const km_v4i*)&sA[cur][((s * 2 + h) * 32 + r) * 16];
+#pragma unroll
+      for (int qt = 0; qt < KM_NQT; ++qt)
+        acc[qt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[qt][s], acc[qt], 0, 0, 0);
+    }
+    bool any = false;
+#pragma unroll
+    for (int qt = 0; qt < KM_NQT; ++qt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) any |= acc[qt][i] > thd[qt];
+    if (__any(any)) {
+      const int rowBase = tile * 32 + 4 * h;
+#pragma unroll
+      for (int qt = 0; qt < KM_NQT; ++qt) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = rowBase + (i & 3) + 8 * (i >> 2);
+          const uint32_t dist = (uint32_t)(256 - acc[qt][i]) >> 1;
+          const uint32_t key = row < len ? ((dist << KNN_IDX_BITS) | (uint32_t)row) : 0xFFFFFFFFu;
+          const uint32_t hi = max(k0[qt], key);
+          k0[qt] = min(k0[qt], key);
+          k1[qt] = min(k1[qt], hi);
+        }
+        thd[qt] = 256 - 2 * (int)(k1[qt] >> KNN_IDX_BITS);
+      }
+    }
+    if (tile + 1 < ntiles) stage(cur ^ 1, pre);
+    __syncthreads();
+  }
+  // ---- the two lanes of a query merge their pairs ------------------------------
+#pragma unroll
+  for (int qt = 0; qt < KM_NQT; ++qt) {
+    const uint32_t p0 = __shfl_xor(k0[qt], 32, 64), p1 = __shfl_xor(k1[qt], 32, 64);
+    const uint32_t m0 = min(k0[qt], p0);
+    const uint32_t m1 = min(max(k0[qt], p0), min(k1[qt], p1));
+    const int qi = blockIdx.x * KM_QPB + (wave * KM_NQT + qt) * 32 + r;
+    if (h == 0 && qi < nq) {
+      const size_t o = ((size_t)seg * nq + qi) * 2;
+      const uint32_t base = index_offset + (uint32_t)t0;
+      const uint32_t mask = (1u << KNN_IDX_BITS) - 1u;
+      out_idx[o] = m0 == 0xFFFFFFFFu ? 0xFFFFFFFFu : base + (m0 & mask);
+      out_idx[o + 1] = m1 == 0xFFFFFFFFu ? 0xFFFFFFFFu : base + (m1 & mask);
+      out_dist[o] = m0 == 0xFFFFFFFFu ? (uint16_t)0xFFFF : (uint16_t)(m0 >> KNN_IDX_BITS);
+      out_dist[o + 1] = m1 == 0xFFFFFFFFu ? (uint16_t)0xFFFF : (uint16_t)(m1 >> KNN_IDX_BITS);
     }
   }
 }
@@ -232,8 +376,15 @@ int orbx_hamming(const uint8_t* a, const uint8_t* b) {
 struct KnnCut { int qblocks; long long segs; int seg_len; };
 static const size_t kPartialBytesPerQuery = 12;   // two uint32 indices + two uint16 distances
 
+// ORBX_KNN2_VALU=1 (timing knob, same results): the vector-ALU scan instead of the matrix-core one
+static bool knn2_use_valu() {
+  static const bool v = [] { const char* e = std::getenv("ORBX_KNN2_VALU"); return e && e[0] == '1'; }();
+  return v;
+}
+
 static int knn2_cut(int nq, int64_t nt, size_t partial_budget, KnnCut* c) {
-  c->qblocks = (nq + KNN_QPL * KNN_BLOCK - 1) / (KNN_QPL * KNN_BLOCK);
+  const int qpb = knn2_use_valu() ? KNN_QPL * KNN_BLOCK : KM_QPB;   // queries per workgroup
+  c->qblocks = (nq + qpb - 1) / qpb;
   long long segs = 1, minSegs = 1;
   if (nt > 0) {
     const long long want = (2048 + c->qblocks - 1) / c->qblocks;
@@ -261,13 +412,14 @@ static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 static int knn2_enqueue(const KnnCut& c, const uint8_t* d_q, int nq, const uint8_t* d_t, int64_t nt,
                         uint32_t index_offset, uint32_t* d_idx, uint16_t* d_dist, uint8_t* partial,
                         hipStream_t s) {
+  auto kern = knn2_use_valu() ? orbx::k_knn2 : orbx::k_knn2_mfma;
   if (c.segs == 1) {
-    hipLaunchKernelGGL(orbx::k_knn2, dim3(c.qblocks, 1), dim3(KNN_BLOCK), 0, s, (const uint32_t*)d_q, nq,
+    hipLaunchKernelGGL(kern, dim3(c.qblocks, 1), dim3(256), 0, s, (const uint32_t*)d_q, nq,
                        (const uint32_t*)d_t, (long long)nt, c.seg_len, index_offset, d_idx, d_dist);
   } else {
     uint8_t* pidx = partial;
     uint8_t* pdist = partial + align256((size_t)c.segs * nq * 8);
-    hipLaunchKernelGGL(orbx::k_knn2, dim3(c.qblocks, (unsigned)c.segs), dim3(KNN_BLOCK), 0, s,
+    hipLaunchKernelGGL(kern, dim3(c.qblocks, (unsigned)c.segs), dim3(256), 0, s,
                        (const uint32_t*)d_q, nq, (const uint32_t*)d_t, (long long)nt, c.seg_len,
                        index_offset, (uint32_t*)pidx, (uint16_t*)pdist);
     hipLaunchKernelGGL(orbx::k_top2_merge, dim3((nq + 255) / 256), dim3(256), 0, s, pidx, (size_t)nq * 8,

@@ -206,6 +206,41 @@ template <class T> inline T readfirstlane(int site, T v) {
 }
 inline void wave_barrier(int site) { (void)wave_gather(site, 0); }
 
+// v_mfma_i32_32x32x32_i8: D = A (32 x 32, signed bytes) * B (32 x 32) + C.  Lane l holds row l & 31
+// of A and column l & 31 of B for the 16 k values 16 (l >> 5) .. + 15 (one per byte of its four
+// dwords), and of C / D column l & 31, rows (i & 3) + 8 (i >> 2) + 4 (l >> 5) for register i.
+typedef int sim_v4i __attribute__((ext_vector_type(4)));
+typedef int sim_v16i __attribute__((ext_vector_type(16)));
+inline sim_v16i mfma_i32_32x32x32_i8(int site, sim_v4i a, sim_v4i b, sim_v16i c) {
+  uint64_t av[2][64], bv[2][64];
+  uint64_t mask = 0;
+  for (int half = 0; half < 2; ++half) {
+    const uint64_t am = ((uint64_t)(uint32_t)a[2 * half + 1] << 32) | (uint32_t)a[2 * half];
+    const uint64_t bm = ((uint64_t)(uint32_t)b[2 * half + 1] << 32) | (uint32_t)b[2 * half];
+    const Gathered ga = wave_gather(site, am);
+    for (int i = 0; i < 64; ++i) av[half][i] = ga.v[i];
+    const Gathered gb = wave_gather(site, bm);
+    for (int i = 0; i < 64; ++i) bv[half][i] = gb.v[i];
+    mask = gb.mask;
+  }
+  if (mask != ~0ull) fail("mfma with inactive lanes", site);
+  const int l = lane_in_wave(), n = l & 31;
+  sim_v16i d = c;
+  for (int i = 0; i < 16; ++i) {
+    const int m = (i & 3) + 8 * (i >> 2) + 4 * (l >> 5);
+    int sum = 0;
+    for (int hh = 0; hh < 2; ++hh)
+      for (int j = 0; j < 16; ++j) {
+        const int ab = (int)(int8_t)(av[j >> 3][m + 32 * hh] >> (8 * (j & 7)));
+        const int bb = (int)(int8_t)(bv[j >> 3][n + 32 * hh] >> (8 * (j & 7)));
+        sum += ab * bb;
+      }
+    d[i] += sum;
+  }
+  return d;
+}
+#define __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, x, y, z) hostsim::mfma_i32_32x32x32_i8(__LINE__, (a), (b), (c))
+
 // v_alignbyte_b32: bytes [sh, sh+4) of the 8-byte value hi:lo
 inline uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) {
   return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (8 * (sh & 3)));
