@@ -126,27 +126,31 @@ __global__ __launch_bounds__(KNN_BLOCK) void k_knn2(const uint32_t* __restrict__
 }
 
 // ---------------------------------------------------------------------------
-// The same scan on the matrix cores.  With every descriptor bit b written as the
-// signed byte 1 - 2 b, the dot product of two descriptors over their 256 bits is
-// 256 - 2 * (Hamming distance): an all-pairs search is a 256-deep int8 matrix
-// product, which v_mfma_i32_32x32x32_i8 computes at about four times the rate the
-// vector ALU reaches with xor + popcount.
+// The same scan on the matrix cores.  With every train bit a written as the byte
+// a (0 or 1) and every query bit b as the signed byte 1 - 2 b, the dot product
+// over the 256 bits is (train bits set where the query's is clear) - (set where
+// the query's is set), and adding the query's own popcount gives the Hamming
+// distance: an all-pairs search is a 256-deep int8 matrix product, which
+// v_mfma_i32_32x32x32_i8 computes at about four times the rate the vector ALU
+// reaches with xor + popcount.
 //
 // A workgroup of four waves owns KM_QPB queries for one train segment.  A wave
 // keeps KM_NQT tiles of 32 queries as the B operand in registers for the whole
-// scan (lane l: query l & 31, bits 16 (l >> 5) .. + 15 of every 32-bit word, one
-// byte per bit).  Train rows come in tiles of 32: the workgroup reads a tile's
-// packed bits (1 KB), writes them to LDS as signed bytes in the order the A
-// operand wants them (k-step, half, row: a wave's 16-byte reads are contiguous),
-// double-buffered, and every wave multiplies the tile with its query tiles.  In
-// the 32 x 32 result a lane holds one query's products with 16 of the tile's rows
+// scan.  Train rows come in tiles of 32: the workgroup reads a tile's packed bits
+// (1 KB), writes them to LDS as bytes in the order the A operand wants them
+// (k-step, half, row: a wave's 16-byte reads are contiguous), double-buffered, and
+// every wave multiplies the tile with its query tiles.  The 32 k values of an
+// instruction may sit in any slot order as long as A and B use the same one (a
+// dot product does not care): step s takes 32-bit word s of the descriptors,
+// lane half h its bit positions j = 4 h + d (d = 0..3 = dword of the operand),
+// byte e of that dword bit 8 e + j - which is what (word >> j) & 0x01010101
+// yields, two instructions per four bits.
+// In the 32 x 32 result a lane holds one query's products with 16 of the tile's rows
 // (row = (i & 3) + 8 (i >> 2) + 4 (l >> 5) for register i), ascending, so the top-2
 // upkeep is per lane: one compare per pair decides whether a row can enter (its
 // distance is below the lane's current second-best; rows arrive in ascending
 // index, so a tie loses), and the key arithmetic runs only in the steps where
 // some lane has such a row.  The two lanes of a query merge their pairs at the end.
-// Any slot order of the 32 k values inside an instruction would do, as long as A
-// and B use the same one: a dot product does not care.
 // ---------------------------------------------------------------------------
 #define KM_NQT 2                              // query tiles of 32 per wave
 #define KM_WAVES 4
@@ -154,19 +158,17 @@ __global__ __launch_bounds__(KNN_BLOCK) void k_knn2(const uint32_t* __restrict__
 typedef int km_v4i __attribute__((ext_vector_type(4)));
 typedef int km_v16i __attribute__((ext_vector_type(16)));
 
-// 4 bits -> 4 bytes: +1 for a clear bit, -1 for a set one
-__device__ __forceinline__ uint32_t pm1_bytes(uint32_t nib) {
-  const uint32_t t = (nib * 0x00204081u) & 0x01010101u;   // bit i -> bit 0 of byte i
-  return (t * 0xFEu) | 0x01010101u;
-}
-__device__ __forceinline__ km_v4i pm1_expand16(uint32_t bits) {
+// bits j0 .. j0 + 3 (+ 8 e for byte e) of a word as four dwords of 0 / 1 bytes
+__device__ __forceinline__ km_v4i bits_to_bytes(uint32_t w, int j0) {
   km_v4i r;
-  r.x = (int)pm1_bytes(bits & 15u);
-  r.y = (int)pm1_bytes((bits >> 4) & 15u);
-  r.z = (int)pm1_bytes((bits >> 8) & 15u);
-  r.w = (int)pm1_bytes((bits >> 12) & 15u);
+  r.x = (int)((w >> j0) & 0x01010101u);
+  r.y = (int)((w >> (j0 + 1)) & 0x01010101u);
+  r.z = (int)((w >> (j0 + 2)) & 0x01010101u);
+  r.w = (int)((w >> (j0 + 3)) & 0x01010101u);
   return r;
 }
+// 0 / 1 bytes -> +1 / -1 bytes
+__device__ __forceinline__ int pm1(int t) { return (int)(((uint32_t)t * 0xFEu) | 0x01010101u); }
 
 __global__ __launch_bounds__(256) void k_knn2_mfma(const uint32_t* __restrict__ q, int nq,
                                                    const uint32_t* __restrict__ t, long long nt,
@@ -179,33 +181,45 @@ __global__ __launch_bounds__(256) void k_knn2_mfma(const uint32_t* __restrict__ 
   const int seg = blockIdx.y;
   const long long t0 = (long long)seg * seg_len;
   const int len = (int)min((long long)seg_len, nt - t0);
-  // ---- the wave's queries as B operands --------------------------------------
+  // ---- the wave's queries as B operands (+1 / -1), and their popcounts --------
   km_v4i bq[KM_NQT][8];
+  int qpop[KM_NQT];
 #pragma unroll
   for (int qt = 0; qt < KM_NQT; ++qt) {
     const int qi = blockIdx.x * KM_QPB + (wave * KM_NQT + qt) * 32 + r;
     const uint4* qp = (const uint4*)(q + (size_t)min(qi, nq - 1) * 8);
     const uint4 a = qp[0], b = qp[1];
     const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    int pc = 0;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) bq[qt][s] = pm1_expand16((w[s] >> (16 * h)) & 0xFFFFu);
+    for (int s = 0; s < 8; ++s) {
+      const km_v4i e = bits_to_bytes(w[s], 4 * h);
+      bq[qt][s].x = pm1(e.x); bq[qt][s].y = pm1(e.y); bq[qt][s].z = pm1(e.z); bq[qt][s].w = pm1(e.w);
+      pc += __builtin_popcount(w[s]);
+    }
+    qpop[qt] = pc;
   }
   uint32_t k0[KM_NQT], k1[KM_NQT];
-  int thd[KM_NQT];   // a row can enter when its product exceeds this (256 - 2 * second-best distance)
+  int thd[KM_NQT];   // a row can enter when its product is below this (second-best distance - popcount)
 #pragma unroll
-  for (int qt = 0; qt < KM_NQT; ++qt) { k0[qt] = 0xFFFFFFFFu; k1[qt] = 0xFFFFFFFFu; thd[qt] = -257; }
+  for (int qt = 0; qt < KM_NQT; ++qt) { k0[qt] = 0xFFFFFFFFu; k1[qt] = 0xFFFFFFFFu; thd[qt] = 1024; }
+  km_v16i zero;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) zero[i] = 0;
 
   // ---- train tiles -------------------------------------------------------------
   const uint32_t* tp = t + (size_t)t0 * 8;
-  const int srow = tid >> 3, sw = tid & 7;   // staging: this thread's row of the tile and word of the row
+  // staging: this thread's row of the tile and word of the row (neighbouring lanes = neighbouring
+  // rows, so that their 16-byte LDS writes are contiguous)
+  const int srow = tid & 31, sw = tid >> 5;
   const int ntiles = (len + 31) >> 5;
   auto fetch = [&](int tile) -> uint32_t {
     const int row = tile * 32 + srow;
     return row < len ? tp[(size_t)row * 8 + sw] : 0u;
   };
   auto stage = [&](int buf, uint32_t bits) {
-    *(km_v4i*)&sA[buf][((sw * 2 + 0) * 32 + srow) * 16] = pm1_expand16(bits & 0xFFFFu);
-    *(km_v4i*)&sA[buf][((sw * 2 + 1) * 32 + srow) * 16] = pm1_expand16(bits >> 16);
+    *(km_v4i*)&sA[buf][((sw * 2 + 0) * 32 + srow) * 16] = bits_to_bytes(bits, 0);
+    *(km_v4i*)&sA[buf][((sw * 2 + 1) * 32 + srow) * 16] = bits_to_bytes(bits, 4);
   };
   uint32_t pre = ntiles > 0 ? fetch(0) : 0u;
   if (ntiles > 0) stage(0, pre);
@@ -215,21 +229,17 @@ __global__ __launch_bounds__(256) void k_knn2_mfma(const uint32_t* __restrict__ 
     if (tile + 1 < ntiles) pre = fetch(tile + 1);
     km_v16i acc[KM_NQT];
 #pragma unroll
-    for (int qt = 0; qt < KM_NQT; ++qt)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[qt][i] = 0;
-#pragma unroll
     for (int s = 0; s < 8; ++s) {
       const km_v4i a = *(const km_v4i*)&sA[cur][((s * 2 + h) * 32 + r) * 16];
 #pragma unroll
       for (int qt = 0; qt < KM_NQT; ++qt)
-        acc[qt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[qt][s], acc[qt], 0, 0, 0);
+        acc[qt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[qt][s], s == 0 ? zero : acc[qt], 0, 0, 0);
     }
     bool any = false;
 #pragma unroll
     for (int qt = 0; qt < KM_NQT; ++qt)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) any |= acc[qt][i] > thd[qt];
+      for (int i = 0; i < 16; ++i) any |= acc[qt][i] < thd[qt];
     if (__any(any)) {
       const int rowBase = tile * 32 + 4 * h;
 #pragma unroll
@@ -237,13 +247,13 @@ __global__ __launch_bounds__(256) void k_knn2_mfma(const uint32_t* __restrict__ 
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int row = rowBase + (i & 3) + 8 * (i >> 2);
-          const uint32_t dist = (uint32_t)(256 - acc[qt][i]) >> 1;
+          const uint32_t dist = (uint32_t)(qpop[qt] + acc[qt][i]);
           const uint32_t key = row < len ? ((dist << KNN_IDX_BITS) | (uint32_t)row) : 0xFFFFFFFFu;
           const uint32_t hi = max(k0[qt], key);
           k0[qt] = min(k0[qt], key);
           k1[qt] = min(k1[qt], hi);
         }
-        thd[qt] = 256 - 2 * (int)(k1[qt] >> KNN_IDX_BITS);
+        thd[qt] = (int)(k1[qt] >> KNN_IDX_BITS) - qpop[qt];
       }
     }
     if (tile + 1 < ntiles) stage(cur ^ 1, pre);
