@@ -31,6 +31,7 @@ LAP = (0, 1000)                  # monocular call, core/src/Frame.cc:360
 HBM_PEAK_GBS = 8000.0
 VALU_PEAK_LANE_OPS = 256 * 64 * 2.4e9          # lane-ops/s: 256 CUs x 64 lanes x 2.4 GHz
 VALU_PEAK_WAVE_INSTS = 256 * 4 * 2.4e9 / 4     # wave instructions/s: 4 SIMDs per CU, 4 cycles each
+MFMA_I8_PEAK_OPS = 5.0e15                      # dense int8 matrix-core peak: twice the 2.5 PFLOP/s of bf16
 
 
 def level_sizes(w, h, nlevels, scale_factor):
@@ -142,7 +143,9 @@ def hamming_bench(torch, orbx, dev, world, rank, nq=1 << 20, nt_per_gpu=1_250_00
     1 M queries against 1.25 M train rows per GPU (10 M rows on 8 GPUs), uniform random 256-bit
     rows, everything resident in HBM.  On one rank the plain device entry point; on N ranks the
     sharded one (queries replicated, train rows sharded, one RCCL all-gather of the top-2
-    records, merge).  Roofline = VALU: 16 lane-ops per pair (8 xor + 8 bcnt)."""
+    records, merge).  The scan runs on the matrix cores (a pair = a 256-deep int8 dot product,
+    512 operations), so its roofline is the dense int8 MFMA peak; the vector-ALU roof the
+    xor + popcount form is bound by (16 lane-ops per pair) is quoted beside it."""
     import ctypes as C
     from orb_slam3_amd._lib import lib, check
     g = torch.Generator(device=dev).manual_seed(1234)
@@ -182,8 +185,14 @@ def hamming_bench(torch, orbx, dev, world, rank, nq=1 << 20, nt_per_gpu=1_250_00
     out = {"metric": "Hamming pairs/s (brute-force 2-NN, train rows sharded over the GPUs)",
            "value": pairs, "unit": "pairs/s", "queries": nq, "train_rows_total": nt_per_gpu * world,
            "train_rows_per_gpu": nt_per_gpu, "ms": sec * 1e3, "n_gpus": world,
-           "roofline": {"bound": "valu", "achieved": pairs * 16 / 1e12, "peak": VALU_PEAK_LANE_OPS * world / 1e12,
-                        "unit": "T lane-ops/s", "frac": pairs * 16 / (VALU_PEAK_LANE_OPS * world)}}
+           "roofline": {"bound": "mfma", "achieved": pairs * 512 / 1e12, "peak": MFMA_I8_PEAK_OPS * world / 1e12,
+                        "unit": "TOP/s (int8)", "frac": pairs * 512 / (MFMA_I8_PEAK_OPS * world),
+                        "kernel": "k_knn2_mfma (v_mfma_i32_32x32x32_i8)",
+                        "times_the_vector_alu_roof": pairs * 16 / (VALU_PEAK_LANE_OPS * world)}}
+    if os.environ.get("ORBX_KNN2_VALU") == "1":
+        out["roofline"] = {"bound": "valu", "achieved": pairs * 16 / 1e12, "peak": VALU_PEAK_LANE_OPS * world / 1e12,
+                           "unit": "T lane-ops/s", "frac": pairs * 16 / (VALU_PEAK_LANE_OPS * world),
+                           "kernel": "k_knn2 (xor + popcount)"}
     if sharded:
         out["exchange"] = {"entry_point": "orbx_knn2_sharded", "collective": "ncclAllGather (in place)",
                            "bytes_per_rank_sent": nq * 12, "bytes_per_rank_received": nq * 12 * world}

@@ -154,6 +154,7 @@ __global__ __launch_bounds__(KNN_BLOCK) void k_knn2(const uint32_t* __restrict__
 // ---------------------------------------------------------------------------
 #define KM_NQT 2                              // query tiles of 32 per wave
 #define KM_WAVES 4
+#define KM_SUB 2                              // train tiles of 32 rows per stage
 #define KM_QPB (KM_WAVES * KM_NQT * 32)       // queries per workgroup
 typedef int km_v4i __attribute__((ext_vector_type(4)));
 typedef int km_v16i __attribute__((ext_vector_type(16)));
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256) void k_knn2_mfma(const uint32_t* __restrict__ 
                                                    int seg_len, uint32_t index_offset,
                                                    uint32_t* __restrict__ out_idx,
                                                    uint16_t* __restrict__ out_dist) {
-  __shared__ __align__(16) uint8_t sA[2][8192];
+  __shared__ __align__(16) uint8_t sA[2][KM_SUB * 8192];   // two stages of KM_SUB tiles of 32 rows
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int seg = blockIdx.y;
@@ -207,56 +208,78 @@ __global__ __launch_bounds__(256) void k_knn2_mfma(const uint32_t* __restrict__ 
 #pragma unroll
   for (int i = 0; i < 16; ++i) zero[i] = 0;
 
-  // ---- train tiles -------------------------------------------------------------
+  // ---- train tiles, KM_SUB of them per stage (one workgroup barrier per stage) ------
   const uint32_t* tp = t + (size_t)t0 * 8;
-  // staging: this thread's row of the tile and word of the row (neighbouring lanes = neighbouring
+  // staging: this thread's row of a tile and word of the row (neighbouring lanes = neighbouring
   // rows, so that their 16-byte LDS writes are contiguous)
   const int srow = tid & 31, sw = tid >> 5;
   const int ntiles = (len + 31) >> 5;
-  auto fetch = [&](int tile) -> uint32_t {
-    const int row = tile * 32 + srow;
-    return row < len ? tp[(size_t)row * 8 + sw] : 0u;
-  };
-  auto stage = [&](int buf, uint32_t bits) {
-    *(km_v4i*)&sA[buf][((sw * 2 + 0) * 32 + srow) * 16] = bits_to_bytes(bits, 0);
-    *(km_v4i*)&sA[buf][((sw * 2 + 1) * 32 + srow) * 16] = bits_to_bytes(bits, 4);
-  };
-  uint32_t pre = ntiles > 0 ? fetch(0) : 0u;
-  if (ntiles > 0) stage(0, pre);
-  __syncthreads();
-  for (int tile = 0; tile < ntiles; ++tile) {
-    const int cur = tile & 1;
-    if (tile + 1 < ntiles) pre = fetch(tile + 1);
-    km_v16i acc[KM_NQT];
+  const int nstages = (ntiles + KM_SUB - 1) / KM_SUB;
+  uint32_t pre[KM_SUB];
+  auto fetch = [&](int stg) {
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const km_v4i a = *(const km_v4i*)&sA[cur][((s * 2 + h) * 32 + r) * 16];
-#pragma unroll
-      for (int qt = 0; qt < KM_NQT; ++qt)
-        acc[qt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[qt][s], s == 0 ? zero : acc[qt], 0, 0, 0);
+    for (int u = 0; u < KM_SUB; ++u) {
+      const int row = (stg * KM_SUB + u) * 32 + srow;
+      pre[u] = row < len ? tp[(size_t)row * 8 + sw] : 0u;
     }
-    bool any = false;
+  };
+  auto stage = [&](int buf) {
 #pragma unroll
-    for (int qt = 0; qt < KM_NQT; ++qt)
+    for (int u = 0; u < KM_SUB; ++u) {
+      *(km_v4i*)&sA[buf][u * 8192 + ((sw * 2 + 0) * 32 + srow) * 16] = bits_to_bytes(pre[u], 0);
+      *(km_v4i*)&sA[buf][u * 8192 + ((sw * 2 + 1) * 32 + srow) * 16] = bits_to_bytes(pre[u], 4);
+    }
+  };
+  if (nstages > 0) { fetch(0); stage(0); }
+  __syncthreads();
+  for (int stg = 0; stg < nstages; ++stg) {
+    const int cur = stg & 1;
+    if (stg + 1 < nstages) fetch(stg + 1);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) any |= acc[qt][i] < thd[qt];
-    if (__any(any)) {
-      const int rowBase = tile * 32 + 4 * h;
+    for (int sub = 0; sub < KM_SUB; ++sub) {
+      const int tile = stg * KM_SUB + sub;
+      const uint8_t* tileA = &sA[cur][sub * 8192];
+      km_v16i acc[KM_NQT];
+#pragma unroll
+      for (int s4 = 0; s4 < 8; s4 += 4) {
+        // four A fragments in flight at a time
+        km_v4i a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] = *(const km_v4i*)&tileA[(((s4 + u) * 2 + h) * 32 + r) * 16];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int qt = 0; qt < KM_NQT; ++qt)
+            acc[qt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[u], bq[qt][s4 + u], s4 + u == 0 ? zero : acc[qt], 0, 0, 0);
+      }
+      // can any of the lane's 16 rows enter?  (smallest product against the threshold; rows past
+      // the segment's end are zeros in LDS and are refused again where the keys are built)
+      bool any = false;
 #pragma unroll
       for (int qt = 0; qt < KM_NQT; ++qt) {
+        int mn = acc[qt][0];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int row = rowBase + (i & 3) + 8 * (i >> 2);
-          const uint32_t dist = (uint32_t)(qpop[qt] + acc[qt][i]);
-          const uint32_t key = row < len ? ((dist << KNN_IDX_BITS) | (uint32_t)row) : 0xFFFFFFFFu;
-          const uint32_t hi = max(k0[qt], key);
-          k0[qt] = min(k0[qt], key);
-          k1[qt] = min(k1[qt], hi);
+        for (int i = 1; i < 16; ++i) mn = min(mn, acc[qt][i]);
+        any |= mn < thd[qt];
+      }
+      if (__any(any)) {
+        const int rowBase = tile * 32 + 4 * h;
+#pragma unroll
+        for (int qt = 0; qt < KM_NQT; ++qt) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int row = rowBase + (i & 3) + 8 * (i >> 2);
+            const uint32_t dist = (uint32_t)(qpop[qt] + acc[qt][i]);
+            const uint32_t key = row < len ? ((dist << KNN_IDX_BITS) | (uint32_t)row) : 0xFFFFFFFFu;
+            const uint32_t hi = max(k0[qt], key);
+            k0[qt] = min(k0[qt], key);
+            k1[qt] = min(k1[qt], hi);
+          }
+          thd[qt] = (int)(k1[qt] >> KNN_IDX_BITS) - qpop[qt];
         }
-        thd[qt] = (int)(k1[qt] >> KNN_IDX_BITS) - qpop[qt];
       }
     }
-    if (tile + 1 < ntiles) stage(cur ^ 1, pre);
+    if (stg + 1 < nstages) stage(cur ^ 1);
     __syncthreads();
   }
   // ---- the two lanes of a query merge their pairs ------------------------------
@@ -397,7 +420,8 @@ static int knn2_cut(int nq, int64_t nt, size_t partial_budget, KnnCut* c) {
   c->qblocks = (nq + qpb - 1) / qpb;
   long long segs = 1, minSegs = 1;
   if (nt > 0) {
-    const long long want = (2048 + c->qblocks - 1) / c->qblocks;
+    // enough workgroups for some twenty rounds of the chip, so that the last round's idle CUs cost little
+    const long long want = ((knn2_use_valu() ? 2048 : 16384) + c->qblocks - 1) / c->qblocks;
     const long long minLen = 512;
     segs = std::max(1LL, std::min(want, (long long)((nt + minLen - 1) / minLen)));
     const long long maxLen = 1LL << KNN_IDX_BITS;
