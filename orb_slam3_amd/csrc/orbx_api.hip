@@ -672,7 +672,12 @@ int orbx_extractor::ensureHostStaging(bool pageableIn, bool pageableOut) {
       HIP_TRY(hipHostMalloc((void**)&h_out[i], (size_t)G * hp.kp_cap * 60, hipHostMallocDefault));
   }
   if ((pageableIn || pageableOut) && !pool && G > 1) {
-    int nt = 6;
+    // packing threads: up to 12 (measured: 4 -> 79 k, 6 -> 93 k, 12 -> 98 k frames/s), within the
+    // job's CPU share where the environment states one and within the machine's CPUs
+    int nt = 12;
+    if (const char* e = std::getenv("OMP_NUM_THREADS")) { const int v = std::atoi(e); if (v >= 1) nt = std::min(nt, v); }
+    const unsigned hw = std::thread::hardware_concurrency();
+    if (hw >= 1) nt = std::min(nt, (int)hw);
     if (const char* e = std::getenv("ORBX_HOST_THREADS")) nt = std::min(std::max(std::atoi(e), 1), 64);
     pool = new (std::nothrow) HostPool(nt - 1);   // the calling thread works too
   }

@@ -97,7 +97,7 @@ int main() {
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   double base = 0;
-  for (int occ = 1; occ <= 2; ++occ) {
+  for (int occ = 1; occ <= 8; occ *= 2) {
     std::printf("-- %d wave(s) per SIMD --\n", occ);
     for (auto& e : es) {
       hipLaunchKernelGGL(e.fn, dim3(waves * occ), dim3(64), 0, 0, d, 1u);
