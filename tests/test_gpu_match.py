@@ -37,6 +37,56 @@ def test_knn2_matches_oracle(oracle, nq, nt):
     assert np.array_equal(idx, ridx)
 
 
+@pytest.mark.parametrize("nq,nt", [(31, 31), (33, 33), (255, 63), (257, 65), (256, 64), (300, 127), (32, 129),
+                                   (65, 4097)])
+def test_knn2_tile_and_workgroup_boundaries(oracle, nq, nt):
+    """Sizes around the matrix-core kernel's units: 32 train rows per tile, 64 per stage, 32 queries
+    per tile, 256 per workgroup."""
+    rng = np.random.default_rng(nq * 7 + nt)
+    q, t = planted(rng, nq, nt)
+    idx, dist = orbx.knn_match2(q, t)
+    ridx, rdist = oracle.knn2(q, t)
+    assert np.array_equal(dist, rdist) and np.array_equal(idx, ridx)
+
+
+def test_knn2_extreme_descriptors(oracle):
+    """All-zero and all-one rows (distances 0 and 256, the ends of the product's range), and rows
+    that differ in a single bit at every position of a 32-bit word."""
+    rng = np.random.default_rng(11)
+    t = rand_desc(rng, 200)
+    t[0] = 0
+    t[1] = 255
+    for b in range(32):
+        bits = np.zeros(256, np.uint8)
+        bits[b] = 1
+        t[2 + b] = np.packbits(bits, bitorder="little")
+    q = np.concatenate([t[:40], 255 - t[:40], rand_desc(rng, 20)])
+    idx, dist = orbx.knn_match2(q, t)
+    ridx, rdist = oracle.knn2(q, t)
+    assert np.array_equal(dist, rdist) and np.array_equal(idx, ridx)
+    assert dist[0, 0] == 0 and dist[1, 0] == 0 and dist.max() <= 256
+
+
+@pytest.mark.needs_real_device
+def test_knn2_matrix_core_and_vector_forms_agree(oracle):
+    """ORBX_KNN2_VALU=1 selects the xor + popcount scan (read once per process): a child process
+    runs it on the same inputs."""
+    import subprocess, sys, os, tempfile
+    rng = np.random.default_rng(21)
+    q, t = planted(rng, 700, 5000)
+    idx, dist = orbx.knn_match2(q, t)
+    with tempfile.TemporaryDirectory() as d:
+        np.save(os.path.join(d, "q.npy"), q)
+        np.save(os.path.join(d, "t.npy"), t)
+        code = ("import numpy as np, orb_slam3_amd as o; q=np.load(r'%s/q.npy'); t=np.load(r'%s/t.npy'); "
+                "i,d=o.knn_match2(q,t); np.save(r'%s/i.npy', i); np.save(r'%s/d.npy', d)" % (d, d, d, d))
+        env = dict(os.environ, ORBX_KNN2_VALU="1")
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        subprocess.check_call([sys.executable, "-c", code], env=env, cwd=root)
+        assert np.array_equal(np.load(os.path.join(d, "i.npy")), idx)
+        assert np.array_equal(np.load(os.path.join(d, "d.npy")), dist)
+
+
 def test_knn2_duplicate_train_rows_tie_break(oracle):
     rng = np.random.default_rng(3)
     t = np.repeat(rand_desc(rng, 50), 40, axis=0)  # every row 40 times -> massive ties
