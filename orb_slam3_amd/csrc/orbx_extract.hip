@@ -1162,9 +1162,11 @@ __global__ __launch_bounds__(64) void k_octree(const Plan* __restrict__ plan,
                                                int* __restrict__ selCount,
                                                uint8_t* __restrict__ workspace, int f0, int l0) {
   extern __shared__ __align__(16) uint8_t smemDyn[];
-  // rotate the level with the frame: workgroups go to the 8 XCDs round-robin, and a fixed
-  // level per XCD would leave the XCD that holds level 0 with more than twice the work
-  const int l = (int)((blockIdx.x + blockIdx.y) % gridDim.x) + l0, f = blockIdx.y + f0;
+  // Level-major grid (x = frame, y = level): the trees of level 0 are by far the longest and a CU
+  // only holds a few of these waves at a time, so they are dispatched first and the short trees of
+  // the small levels fill in behind them; consecutive workgroups (= frames) go to the 8 XCDs
+  // round-robin, so every XCD gets its share of every level.
+  const int l = (int)blockIdx.y + l0, f = (int)blockIdx.x + f0;
   const int lane = lane_id();
   const LevelDesc& L = plan->lv[l];
   const int cap = plan->oct_nodes_cap;
@@ -1844,7 +1846,7 @@ void launch_octree(const Plan& hp, const Plan* dp, const uint32_t* d_cand, const
                    uint32_t* d_flatA, uint32_t* d_flatB, uint32_t* d_sel, int* d_selCount,
                    uint8_t* d_workspace, int l0, int l1, int f0, int nframes, hipStream_t s) {
   if (l1 <= l0) return;
-  dim3 grid(l1 - l0, nframes);
+  dim3 grid(nframes, l1 - l0);
   const size_t lds = hp.oct_ws_bytes ? 0 : octree_lds_bytes(hp);
   hipLaunchKernelGGL(k_octree, grid, dim3(64), lds, s, dp, d_cand, d_cellCount,
                      d_flatA, d_flatB, d_sel, d_selCount, d_workspace, f0, l0);

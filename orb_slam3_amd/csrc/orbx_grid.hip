@@ -143,19 +143,19 @@ __global__ __launch_bounds__(256) void k_features_in_area(const GKP* __restrict_
   const int* cs = cellStart + (size_t)frame * (GRID_CELLS + 1);
   const int* ent = entries + (size_t)frame * cap;
   int found = 0;
-  const int nMinCellX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, minX), r), invW)));
-  const int nMaxCellX = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, minX), r), invW)));
-  const int nMinCellY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, minY), r), invH)));
-  const int nMaxCellY = min(GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, minY), r), invH)));
-  if (nMinCellX < GRID_COLS && nMaxCellX >= 0 && nMinCellY < GRID_ROWS && nMaxCellY >= 0) {
-    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
-    for (int ix = nMinCellX; ix <= nMaxCellX; ++ix)
-      for (int iy = nMinCellY; iy <= nMaxCellY; ++iy) {
+  const int cx0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, minX), r), invW)));
+  const int cx1 = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, minX), r), invW)));
+  const int cy0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, minY), r), invH)));
+  const int cy1 = min(GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, minY), r), invH)));
+  if (cx0 < GRID_COLS && cx1 >= 0 && cy0 < GRID_ROWS && cy1 >= 0) {
+    const bool levelFilter = (minLevel > 0) || (maxLevel >= 0);
+    for (int ix = cx0; ix <= cx1; ++ix)
+      for (int iy = cy0; iy <= cy1; ++iy) {
         const int c = ix * GRID_ROWS + iy;
         for (int e = cs[c]; e < cs[c + 1]; ++e) {
           const int i = ent[e];
           const GKP kp = U[i];
-          if (bCheckLevels) {
+          if (levelFilter) {
             if (kp.octave < minLevel) continue;
             if (maxLevel >= 0 && kp.octave > maxLevel) continue;
           }

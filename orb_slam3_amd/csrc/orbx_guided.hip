@@ -59,23 +59,23 @@ struct GridView {
 template <class F>
 __device__ __forceinline__ void for_each_in_area(const GridView& g, float x, float y, float r, int minLevel,
                                                  int maxLevel, F visit) {
-  const int nMinCellX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, g.minX), r), g.invW)));
-  if (nMinCellX >= GRID_COLS) return;
-  const int nMaxCellX = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, g.minX), r), g.invW)));
-  if (nMaxCellX < 0) return;
-  const int nMinCellY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, g.minY), r), g.invH)));
-  if (nMinCellY >= GRID_ROWS) return;
-  const int nMaxCellY = min(GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, g.minY), r), g.invH)));
-  if (nMaxCellY < 0) return;
-  const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
-  for (int ix = nMinCellX; ix <= nMaxCellX; ++ix)
-    for (int iy = nMinCellY; iy <= nMaxCellY; ++iy) {
+  const int cx0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, g.minX), r), g.invW)));
+  if (cx0 >= GRID_COLS) return;
+  const int cx1 = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, g.minX), r), g.invW)));
+  if (cx1 < 0) return;
+  const int cy0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, g.minY), r), g.invH)));
+  if (cy0 >= GRID_ROWS) return;
+  const int cy1 = min(GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, g.minY), r), g.invH)));
+  if (cy1 < 0) return;
+  const bool levelFilter = (minLevel > 0) || (maxLevel >= 0);
+  for (int ix = cx0; ix <= cx1; ++ix)
+    for (int iy = cy0; iy <= cy1; ++iy) {
       const int c = ix * GRID_ROWS + iy;
       const int e1 = g.cs[c + 1];
       for (int e = g.cs[c]; e < e1; ++e) {
         const int i2 = g.ent[e];
         const GKP kp = g.U[i2];
-        if (bCheckLevels) {
+        if (levelFilter) {
           if (kp.octave < minLevel) continue;
           if (maxLevel >= 0 && kp.octave > maxLevel) continue;
         }
@@ -113,24 +113,24 @@ __device__ __forceinline__ int rotation_bin(float angle1, float angle2) {
 
 // ORBmatcher::ComputeThreeMaxima, matcher.cc:1925-1957
 __device__ void three_maxima(const int* histo, int L, int* ind) {
-  int max1 = 0, max2 = 0, max3 = 0;
-  int ind1 = -1, ind2 = -1, ind3 = -1;
+  int top0 = 0, top1 = 0, top2 = 0;
+  int bin0 = -1, bin1 = -1, bin2 = -1;
   for (int i = 0; i < L; ++i) {
     const int s = histo[i];
-    if (s > max1) {
-      max3 = max2; max2 = max1; max1 = s;
-      ind3 = ind2; ind2 = ind1; ind1 = i;
-    } else if (s > max2) {
-      max3 = max2; max2 = s;
-      ind3 = ind2; ind2 = i;
-    } else if (s > max3) {
-      max3 = s;
-      ind3 = i;
+    if (s > top0) {
+      top2 = top1; top1 = top0; top0 = s;
+      bin2 = bin1; bin1 = bin0; bin0 = i;
+    } else if (s > top1) {
+      top2 = top1; top1 = s;
+      bin2 = bin1; bin1 = i;
+    } else if (s > top2) {
+      top2 = s;
+      bin2 = i;
     }
   }
-  if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
-  else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
-  ind[0] = ind1; ind[1] = ind2; ind[2] = ind3;
+  if ((float)top1 < __fmul_rn(0.1f, (float)top0)) { bin1 = -1; bin2 = -1; }
+  else if ((float)top2 < __fmul_rn(0.1f, (float)top0)) { bin2 = -1; }
+  ind[0] = bin0; ind[1] = bin1; ind[2] = bin2;
 }
 
 }  // namespace
