@@ -286,6 +286,15 @@ int orbx_stereo_match(orbx_extractor* left, orbx_extractor* right, float mbf, fl
  * Nright - monoRight; any of the four outputs may be NULL.  Blocks. */
 int orbx_lapping_knn2(orbx_extractor* left, orbx_extractor* right, int frame, uint32_t* idx, uint16_t* dist,
                       int cap, int* n_query, int* mono_left, int* n_train, int* mono_right);
+/* The same search (core/src/Frame.cc:1159-1177) for frames [0, n_frames) of the
+ * last batched extractions on the two handles in one launch; results stay on
+ * the device.  Asynchronous on the left handle's stream.
+ * orbx_lapping_knn2_download fetches one frame's results in the layout of
+ * orbx_lapping_knn2 (blocks; the right handle must still hold the extraction
+ * the batch call saw). */
+int orbx_lapping_knn2_batch_device(orbx_extractor* left, orbx_extractor* right, int n_frames);
+int orbx_lapping_knn2_download(orbx_extractor* left, int frame, uint32_t* idx, uint16_t* dist, int cap,
+                               int* n_query, int* mono_left, int* n_train, int* mono_right);
 
 /* Frame::ComputeStereoFromRGBD, core/src/Frame.cc:998-1016, for frames
  * [0, n_frames) of the last extraction + grid call on ex (the undistorted x

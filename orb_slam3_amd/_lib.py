@@ -111,6 +111,8 @@ SIGNATURES = {
     "orbx_search_by_projection_points": (C.c_int, [_P, C.c_int, C.c_int, _P, _f32p, _f32p, _i32p, _f32p, _P, _P, _P, _P,
                                                    C.c_float, C.c_float, _P, C.c_int, _i32p, _i32p, _i32p]),
     "orbx_lapping_knn2": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, _i32p, _i32p, _i32p, _i32p]),
+    "orbx_lapping_knn2_batch_device": (C.c_int, [_P, _P, C.c_int]),
+    "orbx_lapping_knn2_download": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, _i32p, _i32p, _i32p, _i32p]),
     "orbx_stereo_from_rgbd_batch_device": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_float]),
     "orbx_search_by_projection_keyframe": (C.c_int, [_P, C.c_int, C.c_int, _P, _f32p, _i32p, _f32p, _P, _P, C.c_float,
                                                      C.c_int, C.c_int, _P, C.c_int, _i32p, _i32p, _i32p]),

@@ -23,6 +23,9 @@
 namespace orbx {
 void launch_pyramid(const Plan& hp, const uint8_t* d_img, int istride, size_t iframe, uint8_t* d_pyr,
                     int f0, int nframes, hipStream_t s);
+void launch_knn2_frames(const uint8_t* descL, int capL, const int* nL, const int* monoL, const uint8_t* descR,
+                        int capR, const int* nR, const int* monoR, uint32_t* idx, uint16_t* dist, int nframes,
+                        hipStream_t s);
 void launch_fast(const Plan& hp, const Plan* dp, const uint8_t* d_pyr, uint32_t* d_cand,
                  int* d_cellCount, int l0, int l1, int f0, int nframes, hipStream_t s);
 void launch_octree(const Plan& hp, const Plan* dp, const uint32_t* d_cand, const int* d_cellCount,
@@ -261,6 +264,11 @@ struct orbx_extractor {
   float* d_stURight = nullptr;
   float* d_stDepth = nullptr;
   int stereoFrames = 0;
+  // lapping-area 2-NN results of this (left) handle for a whole batch, allocated by the first call
+  uint32_t* d_lapIdx = nullptr;    // [max_batch][kp_cap][2]
+  uint16_t* d_lapDist = nullptr;
+  int lapFrames = 0;
+  const orbx_extractor* lapRight = nullptr;
   // frame grid of the last grid call (undistorted keypoints + 64x48 cell CSR)
   float* d_kpsUn = nullptr;
   int* d_cellStart = nullptr;
@@ -374,6 +382,9 @@ void orbx_extractor::freePlan() {
   for (void* b : sbufs) if (b) (void)hipFree(b);
   d_stRowStart = d_stEntries = nullptr; stRightCap = 0;
   d_stBandIdx = d_stBandDist = d_stSad = nullptr; d_stURight = d_stDepth = nullptr; stereoFrames = 0;
+  if (d_lapIdx) (void)hipFree(d_lapIdx);
+  if (d_lapDist) (void)hipFree(d_lapDist);
+  d_lapIdx = nullptr; d_lapDist = nullptr; lapFrames = 0; lapRight = nullptr;
   void* bufs[] = {d_octws, dp, d_img, d_pyr, d_blur, d_cand, d_cellCount, d_flatA, d_flatB, d_sel, d_selCount,
                   d_kps, d_desc, d_work, d_n, d_mono};
   for (void* b : bufs) if (b) (void)hipFree(b);
@@ -789,6 +800,7 @@ void orbx_extractor::afterExtraction(int nframes) {
   // describe keypoints that no longer exist: their download / query calls fail until the
   // corresponding call has run again
   stereoFrames = 0;
+  lapFrames = 0;
   gridFrames = 0;
   bowFrames = 0;
   h_pyr_valid = false;
@@ -1362,6 +1374,65 @@ int orbx_lapping_knn2(orbx_extractor* left, orbx_extractor* right, int frame, ui
   (void)hipFreeAsync(d, s);
   if (st != ORBX_OK) return st;
   if (e != hipSuccess) { last_hip_error = e; return ORBX_ERR_HIP; }
+  return ORBX_OK;
+}
+
+// The same search for frames [0, n_frames) of the two last batched extractions in one launch,
+// results kept on the device (the right handle's extraction must not be redone before the download:
+// its counts are read again there).
+int orbx_lapping_knn2_batch_device(orbx_extractor* left, orbx_extractor* right, int n_frames) {
+  if (!left || !right || left == right || !left->planned || !right->planned || left->device != right->device ||
+      n_frames <= 0)
+    return ORBX_ERR_BAD_ARG;
+  if (n_frames > left->lastFrames || n_frames > right->lastFrames) return ORBX_ERR_BATCH;
+  orbx_extractor* ex = left;
+  if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  if (const int js_ = ex->joinParts()) return js_;
+  if (const int js_ = right->joinParts()) return js_;
+  auto& last_hip_error = ex->last_hip_error;
+  hipStream_t s = ex->stream;
+  if (!ex->evStereo) HIP_TRY(hipEventCreateWithFlags(&ex->evStereo, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(ex->evStereo, right->stream));   // the right extraction runs on its own stream
+  HIP_TRY(hipStreamWaitEvent(s, ex->evStereo, 0));
+  const size_t slots = (size_t)ex->prm.max_batch * ex->hp.kp_cap;
+  if (!ex->d_lapIdx) HIP_TRY(hipMalloc((void**)&ex->d_lapIdx, slots * 8));
+  if (!ex->d_lapDist) HIP_TRY(hipMalloc((void**)&ex->d_lapDist, slots * 4));
+  orbx::launch_knn2_frames(ex->d_desc, ex->hp.kp_cap, ex->d_n, ex->d_mono, right->d_desc, right->hp.kp_cap,
+                           right->d_n, right->d_mono, ex->d_lapIdx, ex->d_lapDist, n_frames, s);
+  HIP_TRY(hipGetLastError());
+  ex->lapFrames = n_frames;
+  ex->lapRight = right;
+  return ORBX_OK;
+}
+
+int orbx_lapping_knn2_download(orbx_extractor* left, int frame, uint32_t* idx, uint16_t* dist, int cap,
+                               int* n_query, int* mono_left, int* n_train, int* mono_right) {
+  if (!left || !left->planned || !left->lapRight || frame < 0 || frame >= left->lapFrames || cap < 0)
+    return ORBX_ERR_BAD_ARG;
+  orbx_extractor* ex = left;
+  const orbx_extractor* right = ex->lapRight;
+  if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  auto& last_hip_error = ex->last_hip_error;
+  hipStream_t s = ex->stream;
+  int h[4] = {0, 0, 0, 0};   // Nleft, monoLeft, Nright, monoRight
+  HIP_TRY(hipMemcpyAsync(&h[0], ex->d_n + frame, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(&h[1], ex->d_mono + frame, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(&h[2], right->d_n + frame, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(&h[3], right->d_mono + frame, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  const int nq = h[0] - h[1], nt = h[2] - h[3];
+  if (n_query) *n_query = nq;
+  if (mono_left) *mono_left = h[1];
+  if (n_train) *n_train = nt;
+  if (mono_right) *mono_right = h[3];
+  if (nq < 0 || nt < 0) return ORBX_ERR_BAD_ARG;
+  if (nq > cap) return ORBX_ERR_CAPACITY;
+  if (nq == 0) return ORBX_OK;
+  if (!idx || !dist) return ORBX_ERR_BAD_ARG;
+  const size_t base = (size_t)frame * ex->hp.kp_cap;
+  HIP_TRY(hipMemcpyAsync(idx, ex->d_lapIdx + base * 2, (size_t)nq * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(dist, ex->d_lapDist + base * 2, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
   return ORBX_OK;
 }
 

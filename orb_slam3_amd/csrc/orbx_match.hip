@@ -171,23 +171,20 @@ __device__ __forceinline__ km_v4i bits_to_bytes(uint32_t w, int j0) {
 // 0 / 1 bytes -> +1 / -1 bytes
 __device__ __forceinline__ int pm1(int t) { return (int)(((uint32_t)t * 0xFEu) | 0x01010101u); }
 
-__global__ __launch_bounds__(256) void k_knn2_mfma(const uint32_t* __restrict__ q, int nq,
-                                                   const uint32_t* __restrict__ t, long long nt,
-                                                   int seg_len, uint32_t index_offset,
-                                                   uint32_t* __restrict__ out_idx,
-                                                   uint16_t* __restrict__ out_dist) {
-  __shared__ __align__(16) uint8_t sA[2][KM_SUB * 8192];   // two stages of KM_SUB tiles of 32 rows
+// The scan of one workgroup: queries [qblock * KM_QPB, + KM_QPB) of q (nq rows) against the len
+// train rows at tp; results (train index = idx_base + row) for query i at out_idx / out_dist + 2 i.
+__device__ __forceinline__ void knn2_mfma_scan(const uint32_t* __restrict__ q, int nq, int qblock,
+                                               const uint32_t* __restrict__ tp, int len, uint32_t idx_base,
+                                               uint32_t* __restrict__ out_idx, uint16_t* __restrict__ out_dist,
+                                               uint8_t (*sA)[KM_SUB * 8192]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int seg = blockIdx.y;
-  const long long t0 = (long long)seg * seg_len;
-  const int len = (int)min((long long)seg_len, nt - t0);
   // ---- the wave's queries as B operands (+1 / -1), and their popcounts --------
   km_v4i bq[KM_NQT][8];
   int qpop[KM_NQT];
 #pragma unroll
   for (int qt = 0; qt < KM_NQT; ++qt) {
-    const int qi = blockIdx.x * KM_QPB + (wave * KM_NQT + qt) * 32 + r;
+    const int qi = qblock * KM_QPB + (wave * KM_NQT + qt) * 32 + r;
     const uint4* qp = (const uint4*)(q + (size_t)min(qi, nq - 1) * 8);
     const uint4 a = qp[0], b = qp[1];
     const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
@@ -209,7 +206,6 @@ __global__ __launch_bounds__(256) void k_knn2_mfma(const uint32_t* __restrict__ 
   for (int i = 0; i < 16; ++i) zero[i] = 0;
 
   // ---- train tiles, KM_SUB of them per stage (one workgroup barrier per stage) ------
-  const uint32_t* tp = t + (size_t)t0 * 8;
   // staging: this thread's row of a tile and word of the row (neighbouring lanes = neighbouring
   // rows, so that their 16-byte LDS writes are contiguous)
   const int srow = tid & 31, sw = tid >> 5;
@@ -288,17 +284,49 @@ __global__ __launch_bounds__(256) void k_knn2_mfma(const uint32_t* __restrict__ 
     const uint32_t p0 = __shfl_xor(k0[qt], 32, 64), p1 = __shfl_xor(k1[qt], 32, 64);
     const uint32_t m0 = min(k0[qt], p0);
     const uint32_t m1 = min(max(k0[qt], p0), min(k1[qt], p1));
-    const int qi = blockIdx.x * KM_QPB + (wave * KM_NQT + qt) * 32 + r;
+    const int qi = qblock * KM_QPB + (wave * KM_NQT + qt) * 32 + r;
     if (h == 0 && qi < nq) {
-      const size_t o = ((size_t)seg * nq + qi) * 2;
-      const uint32_t base = index_offset + (uint32_t)t0;
+      const size_t o = (size_t)qi * 2;
       const uint32_t mask = (1u << KNN_IDX_BITS) - 1u;
-      out_idx[o] = m0 == 0xFFFFFFFFu ? 0xFFFFFFFFu : base + (m0 & mask);
-      out_idx[o + 1] = m1 == 0xFFFFFFFFu ? 0xFFFFFFFFu : base + (m1 & mask);
+      out_idx[o] = m0 == 0xFFFFFFFFu ? 0xFFFFFFFFu : idx_base + (m0 & mask);
+      out_idx[o + 1] = m1 == 0xFFFFFFFFu ? 0xFFFFFFFFu : idx_base + (m1 & mask);
       out_dist[o] = m0 == 0xFFFFFFFFu ? (uint16_t)0xFFFF : (uint16_t)(m0 >> KNN_IDX_BITS);
       out_dist[o + 1] = m1 == 0xFFFFFFFFu ? (uint16_t)0xFFFF : (uint16_t)(m1 >> KNN_IDX_BITS);
     }
   }
+}
+
+// grid (query blocks, train segments): segment seg's results at out + seg * nq * 2
+__global__ __launch_bounds__(256) void k_knn2_mfma(const uint32_t* __restrict__ q, int nq,
+                                                   const uint32_t* __restrict__ t, long long nt,
+                                                   int seg_len, uint32_t index_offset,
+                                                   uint32_t* __restrict__ out_idx,
+                                                   uint16_t* __restrict__ out_dist) {
+  __shared__ __align__(16) uint8_t sA[2][KM_SUB * 8192];   // two stages of KM_SUB tiles of 32 rows
+  const int seg = blockIdx.y;
+  const long long t0 = (long long)seg * seg_len;
+  const int len = (int)min((long long)seg_len, nt - t0);
+  knn2_mfma_scan(q, nq, (int)blockIdx.x, t + (size_t)t0 * 8, len, index_offset + (uint32_t)t0,
+                 out_idx + (size_t)seg * nq * 2, out_dist + (size_t)seg * nq * 2, sA);
+}
+
+// grid (query blocks, frames): per frame the rows [mono, n) of the left descriptors against the
+// rows [mono, n) of the right ones (the lapping-area subsets of a fisheye pair,
+// core/src/Frame.cc:1159-1165); results for left row mono + i at slot frame * capL + i, train
+// indices relative to the right frame's mono
+__global__ __launch_bounds__(256) void k_knn2_mfma_frames(const uint32_t* __restrict__ descL, int capL,
+                                                          const int* __restrict__ nL, const int* __restrict__ monoL,
+                                                          const uint32_t* __restrict__ descR, int capR,
+                                                          const int* __restrict__ nR, const int* __restrict__ monoR,
+                                                          uint32_t* __restrict__ out_idx,
+                                                          uint16_t* __restrict__ out_dist) {
+  __shared__ __align__(16) uint8_t sA[2][KM_SUB * 8192];
+  const int f = blockIdx.y;
+  const int ml = monoL[f], mr = monoR[f];
+  const int nq = nL[f] - ml, nt = nR[f] - mr;
+  if ((int)blockIdx.x * KM_QPB >= nq) return;   // the whole workgroup
+  knn2_mfma_scan(descL + ((size_t)f * capL + ml) * 8, nq, (int)blockIdx.x, descR + ((size_t)f * capR + mr) * 8,
+                 max(nt, 0), 0u, out_idx + (size_t)f * capL * 2, out_dist + (size_t)f * capL * 2, sA);
 }
 
 // Merge partial 2-NN lists by (distance, index); part p holds its nq*2 indices at idx_parts +
@@ -374,6 +402,12 @@ __global__ __launch_bounds__(256) void k_stereo_band(const KP* __restrict__ kl,
 }  // namespace orbx
 
 namespace orbx {
+void launch_knn2_frames(const uint8_t* descL, int capL, const int* nL, const int* monoL, const uint8_t* descR,
+                        int capR, const int* nR, const int* monoR, uint32_t* idx, uint16_t* dist, int nframes,
+                        hipStream_t s) {
+  hipLaunchKernelGGL(k_knn2_mfma_frames, dim3((capL + KM_QPB - 1) / KM_QPB, nframes), dim3(256), 0, s,
+                     (const uint32_t*)descL, capL, nL, monoL, (const uint32_t*)descR, capR, nR, monoR, idx, dist);
+}
 void launch_top2_merge_strided(const uint8_t* idx_parts, size_t idx_stride, const uint8_t* dist_parts,
                                size_t dist_stride, int nparts, int nq, uint32_t* idx, uint16_t* dist,
                                hipStream_t s) {

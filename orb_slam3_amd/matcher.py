@@ -78,6 +78,24 @@ def lapping_knn_match2(ex_left, ex_right, frame=0):
     return idx[:nq.value].copy(), dist[:nq.value].copy(), ml.value, mr.value
 
 
+def lapping_knn_match2_batch(ex_left, ex_right, n_frames):
+    """lapping_knn_match2 for frames [0, n_frames) of the two last batched extractions in one
+    launch; results stay on the device.  Asynchronous; fetch with lapping_knn_download()."""
+    check(lib().orbx_lapping_knn2_batch_device(ex_left._h, ex_right._h, int(n_frames)),
+          "orbx_lapping_knn2_batch_device")
+
+
+def lapping_knn_download(ex_left, frame):
+    """One frame's results of lapping_knn_match2_batch, as lapping_knn_match2 returns them."""
+    cap = ex_left.max_keypoints()
+    idx = np.empty((cap, 2), np.uint32)
+    dist = np.empty((cap, 2), np.uint16)
+    nq, ml, nt, mr = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    check(lib().orbx_lapping_knn2_download(ex_left._h, int(frame), ptr(idx), ptr(dist), cap, C.byref(nq),
+                                           C.byref(ml), C.byref(nt), C.byref(mr)), "orbx_lapping_knn2_download")
+    return idx[:nq.value].copy(), dist[:nq.value].copy(), ml.value, mr.value
+
+
 def compute_stereo_from_rgbd_batch(ex, n_frames, d_depth_ptr, stride_floats, mbf):
     """Frame::ComputeStereoFromRGBD (core/src/Frame.cc:998-1016) for frames [0, n_frames) of the
     last extraction + grid.frame_grid_batch on ex; d_depth_ptr = device address of the float depth

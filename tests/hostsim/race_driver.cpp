@@ -148,6 +148,9 @@ int main(int argc, char** argv) {
     std::vector<uint16_t> ld((size_t)cap * 2);
     int nq = 0, ml = 0, nt = 0, mr = 0;
     CHECK(orbx_lapping_knn2(left, right, 1, li.data(), ld.data(), cap, &nq, &ml, &nt, &mr));
+    CHECK(orbx_lapping_knn2_batch_device(left, right, NF));
+    for (int f = 0; f < NF; ++f)
+      CHECK(orbx_lapping_knn2_download(left, f, li.data(), ld.data(), cap, &nq, &ml, &nt, &mr));
   }
 
   step("stereo association");

@@ -31,6 +31,39 @@ def test_lapping_knn_matches_oracle(oracle, lap_l, lap_r, shift):
     assert len(idx) > 10
 
 
+def test_lapping_knn_batch_equals_per_pair():
+    """One launch for the whole batch (results on the device) against the blocking per-pair call,
+    frames with different subset sizes, one of them with next to no lapping keypoint on the left and
+    one with an empty right frame."""
+    B = 5
+    frames_l = [orbx.textured_frame(61 + i, 512, 512) for i in range(B)]
+    frames_r = [np.roll(f, 7, axis=1) for f in frames_l]
+    frames_l[2] = frames_l[2].copy()
+    frames_l[2][:, 200:] = 90                       # no texture inside the left lapping area
+    frames_r[3] = np.zeros_like(frames_r[3])         # nothing on the right
+    exl = orbx.ORBextractor(1500, 1.2, 8, 20, 7, max_batch=B)
+    exr = orbx.ORBextractor(1500, 1.2, 8, 20, 7, max_batch=B)
+    exl.extract_batch(frames_l, (200, 511))
+    exr.extract_batch(frames_r, (0, 350))
+    per_pair = [orbx.lapping_knn_match2(exl, exr, f) for f in range(B)]
+    orbx.lapping_knn_match2_batch(exl, exr, B)
+    sizes = []
+    for f in range(B):
+        idx, dist, ml, mr = orbx.lapping_knn_download(exl, f)
+        ridx, rdist, rml, rmr = per_pair[f]
+        assert (ml, mr) == (rml, rmr)
+        assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist), f
+        sizes.append(len(idx))
+    assert sizes[2] < 20 and sizes[0] > 100 and len(set(sizes)) > 2
+    assert (per_pair[3][0] == 0xFFFFFFFF).all()
+    from orb_slam3_amd._lib import OrbxError
+    with pytest.raises(OrbxError):
+        orbx.lapping_knn_download(exl, B)            # beyond the batch call
+    exl.extract_batch(frames_l, (200, 511))          # a new extraction invalidates the results
+    with pytest.raises(OrbxError):
+        orbx.lapping_knn_download(exl, 0)
+
+
 def test_lapping_knn_edge_cases():
     from orb_slam3_amd._lib import OrbxError
     img = orbx.textured_frame(5, 376, 240)
