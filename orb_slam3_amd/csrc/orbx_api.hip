@@ -226,8 +226,11 @@ struct orbx_extractor {
   hipEvent_t evFork = nullptr, evJoin[kLanes] = {};
   static const int kMaxParts = 3;
   int maxParts = 2;                   // parts a batch is cut into at most (timing knob ORBX_PARTS)
-  int blurPlace = 0;                  // blur: 0 after the quadtree on the part's stream, 1 beside it on the
-                                      // side stream, 2 before it (timing knob ORBX_SIDE_BLUR)
+  int blurPlace = 3;                  // blur: 3 between pyramid and detection on the part's stream (the order
+                                      // in which the two parts of a batch pair best: the other part's
+                                      // detection then runs beside quadtree, descriptors and pyramid),
+                                      // 0 after the quadtree, 2 after the detection, 1 beside the quadtree
+                                      // on the side stream (timing knob ORBX_SIDE_BLUR)
   hipEvent_t evStart = nullptr, evForkB = nullptr, evPyr[kMaxParts] = {};
   hipEvent_t evForkP[kMaxParts] = {}, evJoinP[kMaxParts] = {}, evDone[kMaxParts] = {};
   hipError_t last_hip_error = hipSuccess;
@@ -774,6 +777,7 @@ int orbx_extractor::enqueuePart(int pk, hipStream_t m, hipStream_t side, hipEven
                                 size_t iframe, int lap0, int lap1) {
   orbx::launch_pyramid(hp, d_images, istride, iframe, d_pyr, f0, n, m);
   if (pyrDone) HIP_TRY(hipEventRecord(pyrDone, m));
+  if (blurPlace == 3) orbx::launch_blur(hp, dp, d_pyr, d_blur, f0, n, m);
   HIP_TRY(hipEventRecord(evDet[pk][0], m));
   orbx::launch_fast(hp, dp, d_pyr, d_cand, d_cellCount, 0, hp.nlevels, f0, n, m);
   HIP_TRY(hipEventRecord(evDet[pk][1], m));
@@ -894,7 +898,7 @@ int orbx_create(const orbx_params* p, orbx_extractor** out) {
   }
   if (const char* e = std::getenv("ORBX_SIDE_BLUR")) {
     const int v = std::atoi(e);
-    if (v >= 0 && v <= 2) ex->blurPlace = v;
+    if (v >= 0 && v <= 3) ex->blurPlace = v;
   }
   for (int k = 0; k < orbx_extractor::kLanes && ok; ++k)
     ok = hipStreamCreateWithFlags(&ex->lane[k], hipStreamNonBlocking) == hipSuccess &&
