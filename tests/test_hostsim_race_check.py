@@ -36,8 +36,15 @@ def run(exe, args, extra_env=None):
 @pytest.mark.parametrize("mode,racy", [("lds-race", True), ("lds-barrier", False), ("lds-wave", False),
                                        ("global-race", True), ("global-atomic", False)])
 def test_detector_controls(built, mode, racy):
-    code, out = run("race_selftest", [mode])
-    reported = "WARNING: ThreadSanitizer: data race" in out
+    # The device-memory control only races when several worker threads of the simulation take
+    # workgroups (those that follow each other on one worker count as ordered): on a loaded
+    # machine one worker can finish all of them before the others start, so a racy control that
+    # stays silent is run again before it counts as a failure of the detector.
+    for attempt in range(3 if racy else 1):
+        code, out = run("race_selftest", [mode])
+        reported = "WARNING: ThreadSanitizer: data race" in out
+        if reported == racy:
+            break
     assert reported == racy, out[-2000:]
     assert code == (66 if racy else 0)
 
