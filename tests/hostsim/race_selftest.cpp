@@ -23,7 +23,7 @@ __global__ void k_neighbour(int* out, int mode) {
 // simulation count as ordered, so the control needs several workers busy at the same time.
 __global__ void k_counter(int* word, int mode) {
   if (threadIdx.x != 0) return;
-  for (int k = 0; k < 20000; ++k) {
+  for (int k = 0; k < 100000; ++k) {
     if (mode == 0) *(volatile int*)word = *(volatile int*)word + 1;
     else atomicAdd(word, 1);
   }
