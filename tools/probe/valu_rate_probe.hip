@@ -72,6 +72,32 @@ DEFINE_KERNEL(k_dpp, "v_add_u32_dpp %0, %0, %1 quad_perm:[1,0,3,2] row_mask:0xf 
 DEFINE_KERNEL(k_pkmaxi, "v_pk_max_i16 %0, %0, %1")
 DEFINE_KERNEL(k_pklshl, "v_pk_lshlrev_b16 %0, 1, %0")
 
+DEFINE_KERNEL(k_rndne, "v_rndne_f32 %0, %0")
+DEFINE_KERNEL(k_cvti, "v_cvt_i32_f32 %0, %0")
+DEFINE_KERNEL(k_cvtsdwa, "v_cvt_f32_i32_sdwa %0, sext(%0) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1")
+DEFINE_KERNEL(k_cvtub, "v_cvt_f32_ubyte1 %0, %0")
+DEFINE_KERNEL(k_addf, "v_add_f32 %0, %0, %1")
+
+// the same for instructions on register pairs
+#define DEFINE_KERNEL64(NAME, ASM)                                                        \
+  __global__ __launch_bounds__(64) void NAME(uint32_t* out, uint32_t seed) {              \
+    double a[CHAINS], b = 1.0 + seed * 1e-9, c = 0.5 + seed * 1e-9;                        \
+    for (int i = 0; i < CHAINS; ++i) a[i] = threadIdx.x * 1e-3 + i + seed;                 \
+    for (int it = 0; it < ITERS; ++it) {                                                   \
+      _Pragma("unroll") for (int i = 0; i < CHAINS; ++i)                                   \
+        asm volatile(ASM : "+v"(a[i]) : "v"(b), "v"(c));                                   \
+    }                                                                                      \
+    double s = 0;                                                                          \
+    for (int i = 0; i < CHAINS; ++i) s += a[i];                                            \
+    out[blockIdx.x * 64 + threadIdx.x] = (uint32_t)(long long)s;                           \
+  }
+DEFINE_KERNEL64(k_pkmulf, "v_pk_mul_f32 %0, %0, %1")
+DEFINE_KERNEL64(k_pkaddf, "v_pk_add_f32 %0, %0, %1")
+DEFINE_KERNEL64(k_pkfmaf, "v_pk_fma_f32 %0, %0, %1, %2")
+DEFINE_KERNEL64(k_addd, "v_add_f64 %0, %0, %1")
+DEFINE_KERNEL64(k_muld, "v_mul_f64 %0, %0, %1")
+DEFINE_KERNEL64(k_fmad, "v_fma_f64 %0, %0, %1, %2")
+
 struct Entry { const char* name; void (*fn)(uint32_t*, uint32_t); };
 
 int main() {
@@ -93,7 +119,11 @@ int main() {
                 {"v_med3_i32", k_med3}, {"v_xad_u32", k_xad}, {"v_lshl_add_u32", k_lshladd},
                 {"v_add_lshl_u32", k_addlshl}, {"v_mbcnt_lo", k_mbcnt}, {"v_not_b32", k_not}, {"v_or_b32", k_or},
                 {"v_mov_b32", k_mov}, {"v_cmp + v_cndmask (pair)", k_cmpcnd}, {"v_add_u32 sdwa", k_sdwa},
-                {"v_add_u32 dpp", k_dpp}, {"v_pk_max_i16", k_pkmaxi}, {"v_pk_lshlrev_b16", k_pklshl}};
+                {"v_add_u32 dpp", k_dpp}, {"v_pk_max_i16", k_pkmaxi}, {"v_pk_lshlrev_b16", k_pklshl},
+                {"v_rndne_f32", k_rndne}, {"v_cvt_i32_f32", k_cvti}, {"v_cvt_f32_i32 sdwa", k_cvtsdwa},
+                {"v_cvt_f32_ubyte1", k_cvtub}, {"v_add_f32", k_addf}, {"v_pk_mul_f32", k_pkmulf},
+                {"v_pk_add_f32", k_pkaddf}, {"v_pk_fma_f32", k_pkfmaf}, {"v_add_f64", k_addd},
+                {"v_mul_f64", k_muld}, {"v_fma_f64", k_fmad}};
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   double base = 0;
