@@ -24,6 +24,15 @@ namespace orbx {
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 
+// Synchronisation inside a one-wave workgroup.  The LDS and vector-memory operations of a wave
+// are performed in program order, so its lanes see each other's writes without a hardware
+// barrier and without waiting for outstanding loads or stores; only the compiler must keep the
+// order.  (__syncthreads() would also drain every outstanding global load and store.)
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 // number of set bits of m below the calling lane
 __device__ __forceinline__ int mbcnt64(unsigned long long m) {
   return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
@@ -485,7 +494,7 @@ __device__ __forceinline__ FastPass fast_pass(const uint8_t* tile, const uint8_t
   const int nry = (ch + 1) >> 1;
   const uint32_t c6 = (uint32_t)(tlow + 1) >> 2;
   if (lane == 0) qcnt[0] = 0;
-  __syncthreads();
+  wave_sync();
   // ---- 2. quick rejection, 4 columns x 2 rows per lane ----------------------
   // Survivors are queued as (task row << 10 | task column << 5 | flag bit): bits 3..9 of an entry
   // are the pixel's column, bit 2 its row inside the task, bit 0 the side (0 dark, 1 bright); a
@@ -528,13 +537,13 @@ __device__ __forceinline__ FastPass fast_pass(const uint8_t* tile, const uint8_t
       base += (uint32_t)rpt << 10;
     }
   }
-  __syncthreads();
+  wave_sync();
   // the map of m shares its LDS with the 6-bit tile, which the quick test is done with
   {
     const int mmq = ((ch + 2) * TS) >> 4;
     for (int i = lane; i < mmq; i += 64) ((uint4*)mm)[i] = make_uint4(0, 0, 0, 0);
   }
-  __syncthreads();
+  wave_sync();
 
   const int nq = qcnt[0];
   res.perPixel = c6 < 1 || nq > qcap;
@@ -548,7 +557,7 @@ __device__ __forceinline__ FastPass fast_pass(const uint8_t* tile, const uint8_t
       const int y = (int)(((float)qi + 0.5f) * rcw), x = qi - y * cw;
       mm[(y + 1) * TS + x + 4] = (uint8_t)fast_m<TS>(tile + (y + 3) * TS + x + 4);
     }
-    __syncthreads();
+    wave_sync();
     for (int qi = lane; qi < np; qi += 64) {
       const int y = (int)(((float)qi + 0.5f) * rcw), x = qi - y * cw;
       const uint8_t* q = mm + (y + 1) * TS + x + 4;
@@ -583,7 +592,7 @@ __device__ __forceinline__ FastPass fast_pass(const uint8_t* tile, const uint8_t
       nc += __popcll(mask);
     }
     res.ncorner = nc;
-    __syncthreads();
+    wave_sync();
     // ---- 4. suppression inside the cell ---------------------------------------
     for (int q0 = 0; q0 < nc; q0 += 64) {
       const int qi = q0 + lane;
@@ -602,7 +611,7 @@ __device__ __forceinline__ FastPass fast_pass(const uint8_t* tile, const uint8_t
     }
   }
   res.anyHi = __ballot(anyHi) != 0ull;
-  __syncthreads();
+  wave_sync();
   return res;
 }
 
@@ -637,7 +646,9 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Plan* __restrict__ plan
   uint32_t* bitsIni = (uint32_t*)(queue + plan->fast_qcap);
   uint32_t* bitsMin = bitsIni + plan->fast_words;
   uint16_t* prefix = (uint16_t*)(bitsMin + plan->fast_words);          // corners before each mask word
-  int* qcnt = (int*)(((uintptr_t)(prefix + plan->fast_words) + 3) & ~(uintptr_t)3);
+  // (the offset is rounded, not the pointer: a pointer that went through an integer would be
+  // accessed with flat instructions instead of LDS ones)
+  int* qcnt = (int*)(smem + ((2 * plan->fast_tile_rows * TS + 2 * plan->fast_qcap + 10 * plan->fast_words + 3) & ~3));
 
   // ---- 1. tile: LDS (row r, col c) = level pixel (X0 - 4 + c, Y0 - 3 + r) ----
   {
@@ -669,7 +680,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Plan* __restrict__ plan
     }
     for (int i = lane; i < nwords; i += 64) { bitsIni[i] = 0; bitsMin[i] = 0; }
   }
-  __syncthreads();
+  wave_sync();
 
   // quick-test task grid: ngx tasks of 4 columns per row of tasks, rpt rows of tasks per trip
   const int ngx = (cw + 3) >> 2;
@@ -717,7 +728,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Plan* __restrict__ plan
       if (wi < nwords) prefix[wi] = (uint16_t)(running + inc - c);
       running += __shfl(inc, 63, 64);
     }
-    __syncthreads();
+    wave_sync();
     for (int q0 = 0; q0 < ps.ncorner; q0 += 64) {
       const int qi = q0 + lane;
       if (qi < ps.ncorner) {
@@ -807,7 +818,7 @@ __device__ __forceinline__ int quadrant_of(uint32_t key, int mx, int my) {
 }
 
 // count step for ord[0..m)
-__device__ void oct_count(const OctState& st, int m) {
+__device__ __forceinline__ void oct_count(const OctState& st, int m) {
   const int lane = lane_id();
   for (int base = 0; base < m; base += 64) {
     const int t = base + lane;
@@ -858,7 +869,7 @@ __device__ void oct_count(const OctState& st, int m) {
 // place step: creation index of every node's first child; returns the number of nodes
 // actually split (all of them, or up to the one that lifts the node total to N when
 // stopAtN), the number of children created and how many of those can be split again.
-__device__ int oct_place(const OctState& st, int m, int n0, int N, bool stopAtN, int* nchOut,
+__device__ __forceinline__ int oct_place(const OctState& st, int m, int n0, int N, bool stopAtN, int* nchOut,
                          int* nExpOut) {
   const int lane = lane_id();
   int childRun = 0, nodeRun = n0, mEff = m;
@@ -926,7 +937,7 @@ __device__ __forceinline__ void oct_write_children(const OctState& st, const QNo
 }
 
 // scatter step for ord[0..mEff)
-__device__ void oct_scatter(const OctState& st, int mEff) {
+__device__ __forceinline__ void oct_scatter(const OctState& st, int mEff) {
   const int lane = lane_id();
   for (int base = 0; base < mEff; base += 64) {
     const int t = base + lane;
@@ -999,7 +1010,7 @@ __device__ void oct_scatter(const OctState& st, int mEff) {
 }
 
 // new list = reverse(newch[0..nch)) ++ [old nodes with cnt != 0, old order]
-__device__ int rebuild_list(const QNode* cur, int n, const QNode* newch, int nch, QNode* nxt) {
+__device__ __forceinline__ int rebuild_list(const QNode* cur, int n, const QNode* newch, int nch, QNode* nxt) {
   const int lane = lane_id();
   for (int i = lane; i < nch; i += 64) nxt[i] = newch[nch - 1 - i];
   int m = nch;
@@ -1016,7 +1027,7 @@ __device__ int rebuild_list(const QNode* cur, int n, const QNode* newch, int nch
 // records of the children that can still be split, in creation order:
 // high word = (key count << 12 | ulx) (the reference's comparison key),
 // low word = position of the child in the rebuilt list.
-__device__ int build_records(const QNode* newch, int nch, orbx_sort::elem_t* rec) {
+__device__ __forceinline__ int build_records(const QNode* newch, int nch, orbx_sort::elem_t* rec) {
   const int lane = lane_id();
   int nrec = 0;
   for (int base = 0; base < nch; base += 64) {
@@ -1043,32 +1054,32 @@ __device__ int build_records(const QNode* newch, int nch, orbx_sort::elem_t* rec
 // a cut, i.e. it is a stable sort inside each final segment.  A segment whose depth
 // budget is spent is heap-sorted serially like the original (rare).
 // Scratch: posA/posB (n entries), segflag (n + 1 bytes), tmp (n elements), stk (3*64 ints).
-__device__ void oct_sort(orbx_sort::elem_t* v, int n, unsigned short* posA, unsigned short* posB,
+__device__ __forceinline__ void oct_sort(orbx_sort::elem_t* v, int n, unsigned short* posA, unsigned short* posB,
                          unsigned char* segflag, orbx_sort::elem_t* tmp, int* stk) {
   using orbx_sort::less;
   const int lane = lane_id();
   if (n <= 1) return;
   for (int i = lane; i <= n; i += 64) segflag[i] = (i == 0 || i == n) ? 1 : 0;
-  __syncthreads();
+  wave_sync();
   if (n > 16) {
     int sp = 0;
     if (lane == 0) { stk[0] = 0; stk[1] = n; stk[2] = 2 * orbx_sort::floor_log2(n); }
     sp = 1;
-    __syncthreads();
+    wave_sync();
     while (sp > 0) {
       --sp;
       int first = stk[3 * sp], last = stk[3 * sp + 1], depth = stk[3 * sp + 2];
-      __syncthreads();
+      wave_sync();
       while (last - first > 16) {
         if (depth == 0) {
           if (lane == 0) orbx_sort::heap_sort_range(v, first, last);
-          __syncthreads();
+          wave_sync();
           break;
         }
         --depth;
         const int mid = first + (last - first) / 2;
         if (lane == 0) orbx_sort::move_median_to_first(v, first, first + 1, mid, last - 1);
-        __syncthreads();
+        wave_sync();
         const orbx_sort::elem_t P = v[first];
         const int lo = first + 1, hi = last;
         int nA = 0, nB = 0;
@@ -1086,7 +1097,7 @@ __device__ void oct_sort(orbx_sort::elem_t* v, int n, unsigned short* posA, unsi
           if (fl) posB[nB + mbcnt64(mask)] = (unsigned short)i;
           nB += __popcll(mask);
         }
-        __syncthreads();
+        wave_sync();
         const int kmax = min(nA, nB);
         int kstar = 0;
         for (int base = 0; base < kmax; base += 64) {
@@ -1112,7 +1123,7 @@ __device__ void oct_sort(orbx_sort::elem_t* v, int n, unsigned short* posA, unsi
         }
         ++sp;
         last = cut;
-        __syncthreads();
+        wave_sync();
       }
     }
   }
@@ -1133,9 +1144,9 @@ __device__ void oct_sort(orbx_sort::elem_t* v, int n, unsigned short* posA, unsi
       tmp[rank] = me;
     }
   }
-  __syncthreads();
+  wave_sync();
   for (int i = lane; i < n; i += 64) v[i] = tmp[i];
-  __syncthreads();
+  wave_sync();
 }
 
 // Test hook: sorts n records in LDS with oct_sort and returns them.
@@ -1148,70 +1159,23 @@ __global__ __launch_bounds__(64) void k_debug_sort(orbx_sort::elem_t* data, int 
   unsigned short* posB = posA + n;
   unsigned char* segflag = (unsigned char*)(posB + n);
   for (int i = threadIdx.x; i < n; i += 64) v[i] = data[i];
-  __syncthreads();
+  wave_sync();
   oct_sort(v, n, posA, posB, segflag, tmp, stk);
   for (int i = threadIdx.x; i < n; i += 64) data[i] = v[i];
 }
 
-__global__ __launch_bounds__(64) void k_octree(const Plan* __restrict__ plan,
-                                               const uint32_t* __restrict__ cand,
-                                               const int* __restrict__ cellCount,
-                                               uint32_t* __restrict__ flatA,
-                                               uint32_t* __restrict__ flatB,
-                                               uint32_t* __restrict__ sel,
-                                               int* __restrict__ selCount,
-                                               uint8_t* __restrict__ workspace, int f0, int l0) {
-  extern __shared__ __align__(16) uint8_t smemDyn[];
-  // Level-major grid (x = frame, y = level): the trees of level 0 are by far the longest and a CU
-  // only holds a few of these waves at a time, so they are dispatched first and the short trees of
-  // the small levels fill in behind them; consecutive workgroups (= frames) go to the 8 XCDs
-  // round-robin, so every XCD gets its share of every level.
-  const int l = (int)blockIdx.y + l0, f = (int)blockIdx.x + f0;
+// The tree of one (frame, level) once its candidates are counted: `st` holds the node arrays and
+// the two key buffers.  Inlined once per kind of memory the caller puts them in, so that every
+// access is an LDS or a global instruction rather than a flat one (a flat access to LDS takes the
+// long way through the vector-memory pipeline and ties the two wait counters together).
+__device__ __forceinline__ void octree_level(const Plan* __restrict__ plan, const LevelDesc& L, OctState st,
+                                             orbx_sort::elem_t* rec, const int* cellpref, int* rootCnt,
+                                             const uint32_t* __restrict__ candL, int nc, int total,
+                                             uint32_t* __restrict__ out, int* __restrict__ selCountSlot) {
   const int lane = lane_id();
-  const LevelDesc& L = plan->lv[l];
-  const int cap = plan->oct_nodes_cap;
-  // node arrays live in LDS; plans whose arrays exceed it (tens of thousands of
-  // features per frame) use a per-(frame, level) slice of a global workspace instead
-  uint8_t* smem = plan->oct_ws_bytes ? workspace + ((size_t)f * plan->nlevels + l) * plan->oct_ws_bytes
-                                     : smemDyn;
-  OctState st;
-  st.cnt4 = (int4*)smem;                                    // 16-byte aligned first
-  st.cur = (QNode*)(st.cnt4 + cap);
-  st.nxt = st.cur + cap;
-  st.newch = st.nxt + cap;
-  orbx_sort::elem_t* rec = (orbx_sort::elem_t*)(st.newch + cap);
-  st.cbase = (int*)(rec + cap);
-  int* cellpref = st.cbase + cap;
-  uint32_t* ldsKeys = (uint32_t*)(cellpref + plan->oct_cells_max + 1);
-  st.ord = (unsigned short*)(ldsKeys + 2 * plan->oct_keys_lds);
-  __shared__ int rootCnt[ORBX_MAX_ROOTS];
-
-  // ---- candidate order = cell-row-major, then (y, x) inside a cell ---------
-  const int nc = L.ncx * L.ncy;
-  const int* cc = cellCount + (size_t)f * plan->cells_per_frame + L.cell_first;
-  int total = 0;
-  for (int base = 0; base < nc; base += 64) {
-    const int c = base + lane;
-    const int v = c < nc ? cc[c] : 0;
-    const int inc = wave_incl_scan(v);
-    if (c < nc) cellpref[c] = total + inc - v;
-    total += __shfl(inc, 63, 64);
-  }
-  if (lane == 0) cellpref[nc] = total;
-  if (lane < ORBX_MAX_ROOTS) rootCnt[lane] = 0;
-  if (total <= plan->oct_keys_lds) {
-    st.bufA = ldsKeys;
-    st.bufB = ldsKeys + plan->oct_keys_lds;
-  } else {
-    st.bufA = flatA + (size_t)f * plan->flat_frame + L.flat_off;
-    st.bufB = flatB + (size_t)f * plan->flat_frame + L.flat_off;
-  }
-  __syncthreads();
-
-  // flatten into B and count keys per root: root = int(x / hX) (extractor.cc:571-574)
-  const uint32_t* candL = cand + (size_t)f * plan->cand_frame + L.cand_off;
   const int nroots = L.n_roots;
   const float hX = L.hX;
+  // flatten into B and count keys per root: root = int(x / hX) (extractor.cc:571-574)
   // four chunks per trip so that the (global) candidate loads of a trip are in flight together
   for (int base = 0; base < total; base += 256) {
     uint32_t key[4];
@@ -1242,7 +1206,7 @@ __global__ __launch_bounds__(64) void k_octree(const Plan* __restrict__ plan,
       }
     }
   }
-  __syncthreads();
+  wave_sync();
   // scatter B -> A grouped by root, order kept
   {
     int rbase[ORBX_MAX_ROOTS];
@@ -1290,61 +1254,49 @@ __global__ __launch_bounds__(64) void k_octree(const Plan* __restrict__ plan,
       acc += c;
     }
   }
-  __syncthreads();
+  wave_sync();
 
   const int N = L.quota;
   int nrec = 0;
   bool finish = false;
+  // whole-level passes (extractor.cc:606-657: every node with more than one key, list order) until
+  // one more could overshoot N, then the final rounds (extractor.cc:665-721: largest nodes first,
+  // stop at N nodes); both kinds of pass run through the same three steps
+  bool finalRounds = false;
   while (!finish) {
-    int prevSize = n;
-    // whole-level pass (extractor.cc:606-657): every node with more than one key, list order
+    const int prevSize = n;
     int m = 0;
-    for (int base = 0; base < n; base += 64) {
-      const int p = base + lane;
-      const bool exp = p < n && qcount(st.cur[p]) > 1;
-      const unsigned long long mask = __ballot(exp);
-      if (exp) st.ord[m + mbcnt64(mask)] = (unsigned short)p;
-      m += __popcll(mask);
+    if (!finalRounds) {
+      for (int base = 0; base < n; base += 64) {
+        const int p = base + lane;
+        const bool exp = p < n && qcount(st.cur[p]) > 1;
+        const unsigned long long mask = __ballot(exp);
+        if (exp) st.ord[m + mbcnt64(mask)] = (unsigned short)p;
+        m += __popcll(mask);
+      }
+    } else {
+      oct_sort(rec, nrec, st.ord, (unsigned short*)st.cbase, (unsigned char*)st.newch,
+               (orbx_sort::elem_t*)st.cnt4, (int*)st.nxt);
+      for (int t = lane; t < nrec; t += 64) st.ord[t] = (unsigned short)(uint32_t)rec[nrec - 1 - t];
+      m = nrec;
     }
-    __syncthreads();
+    wave_sync();
     oct_count(st, m);
-    __syncthreads();
+    wave_sync();
     int nch, nToExpand;
-    oct_place(st, m, n, N, false, &nch, &nToExpand);
-    __syncthreads();
-    oct_scatter(st, m);
-    __syncthreads();
+    const int mEff = oct_place(st, m, n, N, finalRounds, &nch, &nToExpand);
+    wave_sync();
+    oct_scatter(st, mEff);
+    wave_sync();
     n = rebuild_list(st.cur, n, st.newch, nch, st.nxt);
     nrec = build_records(st.newch, nch, rec);
     { QNode* t = st.cur; st.cur = st.nxt; st.nxt = t; }
-    __syncthreads();
-    if (n >= N || n == prevSize) {
-      finish = true;
-    } else if (n + nToExpand * 3 > N) {
-      // final rounds (extractor.cc:665-721): largest nodes first, stop at N nodes
-      while (!finish) {
-        prevSize = n;
-        oct_sort(rec, nrec, st.ord, (unsigned short*)st.cbase, (unsigned char*)st.newch,
-                 (orbx_sort::elem_t*)st.cnt4, (int*)st.nxt);
-        for (int t = lane; t < nrec; t += 64) st.ord[t] = (unsigned short)(uint32_t)rec[nrec - 1 - t];
-        __syncthreads();
-        oct_count(st, nrec);
-        __syncthreads();
-        const int mEff = oct_place(st, nrec, n, N, true, &nch, &nToExpand);
-        __syncthreads();
-        oct_scatter(st, mEff);
-        __syncthreads();
-        n = rebuild_list(st.cur, n, st.newch, nch, st.nxt);
-        nrec = build_records(st.newch, nch, rec);
-        { QNode* t = st.cur; st.cur = st.nxt; st.nxt = t; }
-        __syncthreads();
-        if (n >= N || n == prevSize) finish = true;
-      }
-    }
+    wave_sync();
+    if (n >= N || n == prevSize) finish = true;
+    else if (n + nToExpand * 3 > N) finalRounds = true;
   }
 
   // best key per node: highest score, first one wins ties (extractor.cc:726-742)
-  uint32_t* out = sel + (size_t)f * plan->sel_frame + L.sel_off;
   for (int p = lane; p < n; p += 64) {
     const QNode nd = st.cur[p];
     const uint32_t* keys = (((unsigned)nd.cnt >> 31) ? st.bufB : st.bufA) + nd.start;
@@ -1360,7 +1312,70 @@ __global__ __launch_bounds__(64) void k_octree(const Plan* __restrict__ plan,
     }
     if (p < L.sel_cap) out[p] = best;
   }
-  if (lane == 0) selCount[(size_t)f * plan->nlevels + l] = n < L.sel_cap ? n : L.sel_cap;
+  if (lane == 0) *selCountSlot = n < L.sel_cap ? n : L.sel_cap;
+}
+
+template <bool NODES_WS>
+__global__ __launch_bounds__(64) void k_octree(const Plan* __restrict__ plan,
+                                               const uint32_t* __restrict__ cand,
+                                               const int* __restrict__ cellCount,
+                                               uint32_t* __restrict__ flatA,
+                                               uint32_t* __restrict__ flatB,
+                                               uint32_t* __restrict__ sel,
+                                               int* __restrict__ selCount,
+                                               uint8_t* __restrict__ workspace, int f0, int l0) {
+  extern __shared__ __align__(16) uint8_t smemDyn[];
+  // Level-major grid (x = frame, y = level): the trees of level 0 are by far the longest and a CU
+  // only holds a few of these waves at a time, so they are dispatched first and the short trees of
+  // the small levels fill in behind them; consecutive workgroups (= frames) go to the 8 XCDs
+  // round-robin, so every XCD gets its share of every level.
+  const int l = (int)blockIdx.y + l0, f = (int)blockIdx.x + f0;
+  const int lane = lane_id();
+  const LevelDesc& L = plan->lv[l];
+  const int cap = plan->oct_nodes_cap;
+  // node arrays live in LDS; plans whose arrays exceed it (tens of thousands of
+  // features per frame) use a per-(frame, level) slice of a global workspace instead
+  uint8_t* smem;
+  if constexpr (NODES_WS) smem = workspace + ((size_t)f * plan->nlevels + l) * plan->oct_ws_bytes;
+  else smem = smemDyn;
+  OctState st;
+  st.cnt4 = (int4*)smem;                                    // 16-byte aligned first
+  st.cur = (QNode*)(st.cnt4 + cap);
+  st.nxt = st.cur + cap;
+  st.newch = st.nxt + cap;
+  orbx_sort::elem_t* rec = (orbx_sort::elem_t*)(st.newch + cap);
+  st.cbase = (int*)(rec + cap);
+  int* cellpref = st.cbase + cap;
+  uint32_t* ldsKeys = (uint32_t*)(cellpref + plan->oct_cells_max + 1);
+  st.ord = (unsigned short*)(ldsKeys + 2 * plan->oct_keys_lds);
+  __shared__ int rootCnt[ORBX_MAX_ROOTS];
+
+  // ---- candidate order = cell-row-major, then (y, x) inside a cell ---------
+  const int nc = L.ncx * L.ncy;
+  const int* cc = cellCount + (size_t)f * plan->cells_per_frame + L.cell_first;
+  int total = 0;
+  for (int base = 0; base < nc; base += 64) {
+    const int c = base + lane;
+    const int v = c < nc ? cc[c] : 0;
+    const int inc = wave_incl_scan(v);
+    if (c < nc) cellpref[c] = total + inc - v;
+    total += __shfl(inc, 63, 64);
+  }
+  if (lane == 0) cellpref[nc] = total;
+  if (lane < ORBX_MAX_ROOTS) rootCnt[lane] = 0;
+  wave_sync();
+  const uint32_t* candL = cand + (size_t)f * plan->cand_frame + L.cand_off;
+  uint32_t* out = sel + (size_t)f * plan->sel_frame + L.sel_off;
+  int* selCountSlot = selCount + (size_t)f * plan->nlevels + l;
+  if (total <= plan->oct_keys_lds) {
+    st.bufA = ldsKeys;
+    st.bufB = ldsKeys + plan->oct_keys_lds;
+    octree_level(plan, L, st, rec, cellpref, rootCnt, candL, nc, total, out, selCountSlot);
+  } else {
+    st.bufA = flatA + (size_t)f * plan->flat_frame + L.flat_off;
+    st.bufB = flatB + (size_t)f * plan->flat_frame + L.flat_off;
+    octree_level(plan, L, st, rec, cellpref, rootCnt, candL, nc, total, out, selCountSlot);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1848,7 +1863,7 @@ void launch_octree(const Plan& hp, const Plan* dp, const uint32_t* d_cand, const
   if (l1 <= l0) return;
   dim3 grid(nframes, l1 - l0);
   const size_t lds = hp.oct_ws_bytes ? 0 : octree_lds_bytes(hp);
-  hipLaunchKernelGGL(k_octree, grid, dim3(64), lds, s, dp, d_cand, d_cellCount,
+  hipLaunchKernelGGL(hp.oct_ws_bytes ? k_octree<true> : k_octree<false>, grid, dim3(64), lds, s, dp, d_cand, d_cellCount,
                      d_flatA, d_flatB, d_sel, d_selCount, d_workspace, f0, l0);
 }
 
@@ -1894,7 +1909,7 @@ int octree_set_lds_limit(const Plan& hp) {
   const size_t need = octree_lds_bytes(hp) + 256;
   if (need > 160 * 1024) return -1;
   if (need > 64 * 1024) {
-    if (hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)k_octree<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)need) != hipSuccess)
       return -1;
   }
