@@ -649,6 +649,37 @@ int orbx_extractor::buildPlan(int W, int H) {
     L.xblk = (const uint16_t*)dxb; L.yblk = (const uint16_t*)dyb;
   }
   if (resizeLds + 64 > 60 * 1024) return ORBX_ERR_UNSUPPORTED;
+  {
+    // the detection kernel's cell table
+    std::vector<orbx::FastCell> cells((size_t)hp.cells_per_frame);
+    for (int l = 0; l < nl; ++l) {
+      const LevelDesc& L = hp.lv[l];
+      for (int cell = 0; cell < L.ncx * L.ncy; ++cell) {
+        const int ci = cell / L.ncx, cj = cell - ci * L.ncx;
+        const int X0 = ORBX_EDGE + cj * L.wCell, Y0 = ORBX_EDGE + ci * L.hCell;
+        const int cw = std::min(L.wCell, L.w - ORBX_EDGE - X0), chh = std::min(L.hCell, L.h - ORBX_EDGE - Y0);
+        const int shift = (X0 + 15) & 3;   // planes and rows are 64-byte aligned
+        const int ngx = (cw + 3) >> 2;
+        orbx::FastCell c;
+        c.xy = (uint32_t)X0 | ((uint32_t)Y0 << 16);
+        c.geo = (uint32_t)cw | ((uint32_t)chh << 8) | ((uint32_t)l << 16) | ((uint32_t)shift << 20) |
+                ((uint32_t)(L.pstride / 64) << 24);
+        c.cand = L.cand_off + (uint32_t)cell * (uint32_t)L.cand_cap_cell;
+        c.tile = (uint32_t)((size_t)(Y0 - 3 + ORBX_EDGE) * L.pstride + (size_t)(X0 - 4 + ORBX_EDGE - shift));
+        c.pyr64 = (uint32_t)(L.pyr_off / 64);
+        c.plane64 = (uint32_t)(L.pyr_plane / 64);
+        // floor(a / ngx) = (a * magic) >> 16 for 0 <= a <= 64 (ngx <= 64)
+        c.magic = 65536u / (uint32_t)ngx + 1u;
+        c.pad = 0;
+        if (L.pstride / 64 > 255 || L.pyr_off / 64 > 0xffffffffull || cw > 255 || chh > 255) return ORBX_ERR_UNSUPPORTED;
+        cells[(size_t)L.cell_first + cell] = c;
+      }
+    }
+    void* dcells = nullptr;
+    HIP_TRY(hipMalloc(&dcells, cells.size() * sizeof(orbx::FastCell) + 32)); d_taps.push_back(dcells);
+    HIP_TRY(hipMemcpy(dcells, cells.data(), cells.size() * sizeof(orbx::FastCell), hipMemcpyHostToDevice));
+    hp.fast_cells = (const orbx::FastCell*)dcells;
+  }
   HIP_TRY(hipMalloc((void**)&dp, sizeof(Plan)));
   HIP_TRY(hipMemcpy(dp, &hp, sizeof(Plan), hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc((void**)&d_img, (size_t)B * W * H));

@@ -110,9 +110,11 @@ __global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t* __restrict__ 
       const int py = py0 + r;
       if (py >= prows) break;
       const int sy = reflect101(py - ORBX_EDGE, H);
-      const uintptr_t a = (uintptr_t)(fimg + (size_t)sy * istride + (P - ORBX_EDGE));
-      const int sh = (int)(a & 3);
-      const uint8_t* ap = (const uint8_t*)(a - sh);
+      // (the aligned address is formed from the offset, not by masking the pointer's integer
+      // value: such a pointer would be accessed with flat instead of global loads)
+      const size_t off = (size_t)sy * istride + (P - ORBX_EDGE);
+      const int sh = (int)(((uintptr_t)fimg + off) & 3);
+      const uint8_t* ap = fimg + (off - sh);
       const U4A4 v = *(const U4A4*)ap;
       const uint32_t v4 = *(const uint32_t*)(ap + 16);
       uint4 out;
@@ -410,10 +412,6 @@ __device__ __forceinline__ int fast_m_sel(const uint8_t* c, int s8) {
   return max(best - v, 0);
 }
 
-// floor(65536 / n) + 1: floor(a / n) = (a * magic) >> 16 for 0 <= a <= 64, 1 <= n <= 23
-__constant__ uint32_t c_div_magic[24] = {0,    65537, 32769, 21846, 16385, 13108, 10923, 9363, 8193, 7282, 6554, 5958,
-                                         5462, 5042,  4682,  4370,  4097,  3856,  3641,  3450, 3277, 3121, 2979, 2850};
-
 // Quick corner test for the four pixels at window bytes 4..7 of window row WR, four pixels per
 // instruction on pixel values cut to 6 bits (bits 6 and 7 of a byte free, so that a per-byte
 // comparison can neither carry nor borrow across bytes and needs no saturation).  R = 8 window
@@ -617,6 +615,7 @@ __device__ __forceinline__ FastPass fast_pass(const uint8_t* tile, const uint8_t
 
 template <int TS>
 __global__ __launch_bounds__(64) void k_fast_cells(const Plan* __restrict__ plan,
+                                                   const FastCell* __restrict__ cells,
                                                    const uint8_t* __restrict__ pyr,
                                                    uint32_t* __restrict__ cand,
                                                    int* __restrict__ cellCount, int f0, int cell0,
@@ -628,14 +627,10 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Plan* __restrict__ plan
   const int fr = unit / ncells;
   const int f = fr + f0;
   const int cellg = unit - fr * ncells + cell0;
-  int l = 0;
-  while (l + 1 < plan->nlevels && cellg >= plan->lv[l + 1].cell_first) ++l;
-  const LevelDesc& L = plan->lv[l];
-  const int cell = cellg - L.cell_first;
-  const int ci = cell / L.ncx, cj = cell - ci * L.ncx;
-  const int X0 = ORBX_EDGE + cj * L.wCell, Y0 = ORBX_EDGE + ci * L.hCell;
-  const int cw = min(L.wCell, L.w - ORBX_EDGE - X0);
-  const int ch = min(L.hCell, L.h - ORBX_EDGE - Y0);
+  // all the kernel needs to know about the cell: one 32-byte record of the plan's cell table
+  const FastCell c = cells[cellg];
+  const int X0 = (int)(c.xy & 0xFFFF), Y0 = (int)(c.xy >> 16);
+  const int cw = (int)(c.geo & 0xFF), ch = (int)((c.geo >> 8) & 0xFF);
   const int np = cw * ch;
   const int nwords = (np + 31) >> 5;
 
@@ -652,13 +647,13 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Plan* __restrict__ plan
 
   // ---- 1. tile: LDS (row r, col c) = level pixel (X0 - 4 + c, Y0 - 3 + r) ----
   {
-    const int shift = (X0 + 15) & 3;  // planes and rows are 64-byte aligned
-    const uint8_t* g0 = pyr + L.pyr_off + (size_t)f * L.pyr_plane +
-                        (size_t)(Y0 - 3 + ORBX_EDGE) * L.pstride + (X0 - 4 + ORBX_EDGE - shift);
+    // planes and rows are 64-byte aligned; the record holds the aligned start of the first row
+    const int shift = (int)((c.geo >> 20) & 3), pstride = (int)(c.geo >> 24) << 6;
+    const uint8_t* g0 = pyr + ((size_t)c.pyr64 << 6) + (size_t)f * ((size_t)c.plane64 << 6) + c.tile;
     // one lane = one tile row: dword-aligned 16-byte loads plus one more dword, shifted into
     // place with v_alignbyte, 16-byte LDS stores of the pixels and of their 6-bit cut
     for (int r = lane; r < ch + 6; r += 64) {
-      const uint8_t* gp = g0 + (size_t)r * L.pstride;
+      const uint8_t* gp = g0 + (size_t)r * pstride;
       U4A4 v[TS / 16];
 #pragma unroll
       for (int n = 0; n < TS / 16; ++n) v[n] = *(const U4A4*)(gp + 16 * n);
@@ -684,7 +679,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Plan* __restrict__ plan
 
   // quick-test task grid: ngx tasks of 4 columns per row of tasks, rpt rows of tasks per trip
   const int ngx = (cw + 3) >> 2;
-  const uint32_t magic = c_div_magic[ngx];
+  const uint32_t magic = c.magic;
   const int rpt = (int)((64u * magic) >> 16);
   const int lr = (int)(((uint32_t)lane * magic) >> 16), gx = lane - lr * ngx;
 
@@ -715,7 +710,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Plan* __restrict__ plan
   const uint32_t* bits = useIni ? bitsIni : bitsMin;
 
   // ---- 5. ordered output: the corners of the chosen mask in raster order -----------
-  uint32_t* out = cand + (size_t)f * plan->cand_frame + L.cand_off + (size_t)cell * L.cand_cap_cell;
+  uint32_t* out = cand + (size_t)f * plan->cand_frame + c.cand;
   int running = 0;
   if (!ps.perPixel) {
     // a corner's place = mask bits before it: those of the earlier words (scan) + those below
@@ -1841,13 +1836,13 @@ void launch_fast(const Plan& hp, const Plan* dp, const uint8_t* d_pyr, uint32_t*
   const int ts = hp.fast_ts;
   const size_t lds = fast_lds_bytes(hp, ts);
   if (ts == 48)
-    hipLaunchKernelGGL(k_fast_cells<48>, grid, dim3(64), lds, s, dp, d_pyr, d_cand, d_cellCount, f0, cell0,
+    hipLaunchKernelGGL(k_fast_cells<48>, grid, dim3(64), lds, s, dp, hp.fast_cells, d_pyr, d_cand, d_cellCount, f0, cell0,
                        ncells, nunits, chunk);
   else if (ts == 64)
-    hipLaunchKernelGGL(k_fast_cells<64>, grid, dim3(64), lds, s, dp, d_pyr, d_cand, d_cellCount, f0, cell0,
+    hipLaunchKernelGGL(k_fast_cells<64>, grid, dim3(64), lds, s, dp, hp.fast_cells, d_pyr, d_cand, d_cellCount, f0, cell0,
                        ncells, nunits, chunk);
   else
-    hipLaunchKernelGGL(k_fast_cells<80>, grid, dim3(64), lds, s, dp, d_pyr, d_cand, d_cellCount, f0, cell0,
+    hipLaunchKernelGGL(k_fast_cells<80>, grid, dim3(64), lds, s, dp, hp.fast_cells, d_pyr, d_cand, d_cellCount, f0, cell0,
                        ncells, nunits, chunk);
 }
 

@@ -71,6 +71,18 @@ struct LevelDesc {
   int rs_rows;           // rows such a window would need
 };
 
+// What k_fast_cells needs to know about one detection cell of a frame (all levels, in cell order).
+struct FastCell {
+  uint32_t xy;       // X0 | Y0 << 16: level coordinates of the cell's first pixel
+  uint32_t geo;      // width | height << 8 | level << 16 | load shift << 20 | (row stride / 64) << 24
+  uint32_t cand;     // the cell's first slot in a frame's candidate buffer
+  uint32_t tile;     // byte offset, inside the level's padded plane, of the aligned start of the tile's first row
+  uint32_t pyr64;    // the level's planes in the pyramid buffer, / 64
+  uint32_t plane64;  // bytes per plane, / 64
+  uint32_t magic;    // 65536 / (quick-test tasks per row), rounded up: row = lane * magic >> 16
+  uint32_t pad;
+};
+
 struct Plan {
   int nlevels, W, H;
   int ini_th, min_th;
@@ -87,6 +99,7 @@ struct Plan {
   // 1: detect at iniThFAST first and at minThFAST only in cells that found nothing; 0: one pass
   // at the lower threshold that serves both (same results; kept switchable for timing)
   int fast_two_pass;
+  const FastCell* fast_cells;   // [cells_per_frame]
   int blur_waves;        // waves per workgroup of the blur kernel, 4 or 1 (timing knob)
   int pyr_waves;         // waves per workgroup of the pyramid kernels (timing knob; results do not change)
   int oct_nodes_cap;     // quadtree node slots (max over levels)
