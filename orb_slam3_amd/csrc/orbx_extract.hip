@@ -1471,10 +1471,15 @@ __global__ __launch_bounds__(256) void k_assemble(const Plan* __restrict__ plan,
       ((int*)o)[5] = l;
       ((int*)o)[6] = -1;
       WorkItem wi;
-      wi.level = l;
-      wi.xy = ((key & 0xFFF) + ORBX_DET_ORG) | ((((key >> 12) & 0xFFF) + ORBX_DET_ORG) << 16);
+      const LevelDesc& L = plan->lv[l];
+      const int cx = (int)(key & 0xFFF) + ORBX_DET_ORG, cy = (int)((key >> 12) & 0xFFF) + ORBX_DET_ORG;
+      wi.pyr_win = L.pyr_off + (size_t)f * L.pyr_plane + (size_t)(cy + ORBX_EDGE - 15) * L.pstride +
+                   (size_t)((cx + ORBX_EDGE - 15) & ~3);
+      wi.blur_win = L.blur_off + (size_t)f * L.blur_plane + (size_t)(cy - 18) * L.bstride + (size_t)((cx - 18) & ~3);
+      wi.xy = (uint32_t)cx | ((uint32_t)cy << 16);
       wi.dst = dst;
-      wi.pad = 0;
+      wi.strides = (uint32_t)L.pstride | ((uint32_t)L.bstride << 16);
+      wi.level = l;
       const int yl = (int)((key >> 12) & 0xFFF) + ORBX_DET_ORG;
       wout[atomicAdd(&binCur[l * 32 + min(31, (yl * 32) / plan->lv[l].h)], 1)] = wi;
     }
@@ -1654,9 +1659,8 @@ __global__ __launch_bounds__(64) void k_orient_describe(const Plan* __restrict__
   const int k = kbase + g;
   const bool valid = k < n;
   const WorkItem wi = work[(size_t)f * plan->kp_cap + (valid ? k : n - 1)];
-  const LevelDesc& L = plan->lv[wi.level];
-  const int cx = wi.xy & 0xFFFF, cy = wi.xy >> 16;
-  const int ps = L.pstride, bs = L.bstride;
+  const int cx = wi.xy & 0xFFFF;
+  const int ps = (int)(wi.strides & 0xFFFF), bs = (int)(wi.strides >> 16);
 
   // ---- IC_Angle on the un-blurred level (extractor.cc:75-99) ----------------
   // the 31 x 31 patch goes through the same LDS window as the blurred one below
@@ -1665,7 +1669,7 @@ __global__ __launch_bounds__(64) void k_orient_describe(const Plan* __restrict__
   int m10 = 0, m01 = 0;
   {
     const int px0 = (cx + ORBX_EDGE - 15) & ~3;   // padded column of the window's first dword
-    const uint8_t* pbase = pyr + L.pyr_off + (size_t)f * L.pyr_plane + (size_t)(cy + ORBX_EDGE - 15) * ps + px0;
+    const uint8_t* pbase = pyr + wi.pyr_win;
     uint4 st2[IC_STAGE];
 #pragma unroll
     for (int u = 0; u < IC_STAGE; ++u) {
@@ -1735,7 +1739,7 @@ __global__ __launch_bounds__(64) void k_orient_describe(const Plan* __restrict__
   // with row-wise 16-byte loads (issued before the trigonometry so they overlap it); the
   // rotated samples are then LDS byte reads instead of scattered global gathers.
   const int bx0 = (cx - 18) & ~3;
-  const uint8_t* wbase = blur + L.blur_off + (size_t)f * L.blur_plane + (size_t)(cy - 18) * bs + bx0;
+  const uint8_t* wbase = blur + wi.blur_win;
   uint4 stage[DESC_STAGE];
 #pragma unroll
   for (int u = 0; u < DESC_STAGE; ++u) {

@@ -111,12 +111,16 @@ struct Plan {
   LevelDesc lv[ORBX_MAX_LEVELS];
 };
 
-// One unit of work for the orientation + descriptor kernel.
+// One unit of work for the orientation + descriptor kernel: where the keypoint's two windows
+// start (so that the kernel's first loads depend on nothing but this record) and where its
+// results go.
 struct WorkItem {
+  uint64_t pyr_win;   // byte offset in the pyramid buffer of the 31-row patch window: row cy - 15, the dword that holds column cx - 15
+  uint64_t blur_win;  // byte offset in the blurred buffer of the 37-row sample window: row cy - 18, the dword that holds column cx - 18
+  uint32_t xy;        // x | y << 16, level coordinates
+  int dst;            // output slot inside the frame
+  uint32_t strides;   // row stride of the level's padded plane | row stride of its blurred plane << 16
   int level;
-  uint32_t xy;   // x | y << 16, level coordinates
-  int dst;       // output slot inside the frame
-  int pad;
 };
 
 }  // namespace orbx
