@@ -629,6 +629,13 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Plan* __restrict__ plan
   const int cellg = unit - fr * ncells + cell0;
   // all the kernel needs to know about the cell: one 32-byte record of the plan's cell table
   const FastCell c = cells[cellg];
+  // (everything that comes from the plan is read here, in one batch of scalar loads beside the
+  // record's: a load further down would wait for its own round trip)
+  const int ini = plan->ini_th, mn = plan->min_th;
+  const int qcap = plan->fast_qcap;
+  const bool twoPass = plan->fast_two_pass != 0;
+  const size_t candFrame = plan->cand_frame;
+  const int cellsPerFrame = plan->cells_per_frame;
   const int X0 = (int)(c.xy & 0xFFFF), Y0 = (int)(c.xy >> 16);
   const int cw = (int)(c.geo & 0xFF), ch = (int)((c.geo >> 8) & 0xFF);
   const int np = cw * ch;
@@ -638,7 +645,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Plan* __restrict__ plan
   uint8_t* q6 = tile + plan->fast_tile_rows * TS;         // the same pixels cut to 6 bits (quick test)
   uint8_t* mm = q6;                                       // fast_mm_rows x TS, once the quick test is done
   uint16_t* queue = (uint16_t*)(q6 + plan->fast_tile_rows * TS);
-  uint32_t* bitsIni = (uint32_t*)(queue + plan->fast_qcap);
+  uint32_t* bitsIni = (uint32_t*)(queue + qcap);
   uint32_t* bitsMin = bitsIni + plan->fast_words;
   uint16_t* prefix = (uint16_t*)(bitsMin + plan->fast_words);          // corners before each mask word
   // (the offset is rounded, not the pointer: a pointer that went through an integer would be
@@ -690,11 +697,9 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Plan* __restrict__ plan
   // second pass repeat the quick test.
   // When iniThFAST <= minThFAST (or the plan asks for it) one pass at the lower threshold serves
   // both.
-  const int ini = plan->ini_th, mn = plan->min_th;
-  const int qcap = plan->fast_qcap;
   FastPass ps;
   bool useIni;
-  if (ini > mn && plan->fast_two_pass) {
+  if (ini > mn && twoPass) {
     ps = fast_pass<TS>(tile, q6, mm, queue, qcnt, qcap, cw, ch, lane, lr, gx, rpt, ini, ini, bitsIni, 0, nullptr);
     useIni = ps.anyHi;
     if (!useIni) {
@@ -710,7 +715,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Plan* __restrict__ plan
   const uint32_t* bits = useIni ? bitsIni : bitsMin;
 
   // ---- 5. ordered output: the corners of the chosen mask in raster order -----------
-  uint32_t* out = cand + (size_t)f * plan->cand_frame + c.cand;
+  uint32_t* out = cand + (size_t)f * candFrame + c.cand;
   int running = 0;
   if (!ps.perPixel) {
     // a corner's place = mask bits before it: those of the earlier words (scan) + those below
@@ -759,7 +764,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const Plan* __restrict__ plan
       running += __shfl(inc, 63, 64);
     }
   }
-  if (lane == 0) cellCount[(size_t)f * plan->cells_per_frame + cellg] = running;
+  if (lane == 0) cellCount[(size_t)f * cellsPerFrame + cellg] = running;
 }
 
 // ---------------------------------------------------------------------------
