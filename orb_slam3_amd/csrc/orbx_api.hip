@@ -535,6 +535,8 @@ int orbx_extractor::buildPlan(int W, int H) {
     hp.fast_two_pass = (e && e[0] == '1') ? 0 : 1;
     hp.blur_waves = 1;
     if (const char* bw = std::getenv("ORBX_BLUR_WAVES")) hp.blur_waves = std::atoi(bw) == 4 ? 4 : 1;
+    hp.pyr_xcd = 1;
+    if (const char* px = std::getenv("ORBX_PYR_XCD")) hp.pyr_xcd = px[0] != '0';
     hp.pyr_waves = 2;
     if (const char* pw = std::getenv("ORBX_PYR_WAVES")) {
       const int v = std::atoi(pw);

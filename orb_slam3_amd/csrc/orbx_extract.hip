@@ -90,18 +90,39 @@ __device__ __forceinline__ int xcd_contiguous_unit(int chunk) {
   return (b & 7) * chunk + (b >> 3);
 }
 
+// The same for a (gx, gy, gz) arrangement of workgroups launched as 8 * chunk: x runs fastest
+// inside an XCD's range, so the workgroups that share source lines - the column blocks of a row
+// block, and row blocks above each other - fetch them through one L2 (handed out round-robin,
+// neighbouring blocks each fetched the shared lines into an L2 of their own: the level chain read
+// 1.4 times its source bytes past the L2).  False for the surplus workgroups.
+__device__ __forceinline__ bool xcd_contiguous_block(int chunk, int gx, int gy, int nblocks, int& bx, int& by,
+                                                     int& bz) {
+  // chunk 0 (timing knob): workgroups taken in launch order, i.e. neighbours on different XCDs
+  const int u = chunk > 0 ? xcd_contiguous_unit(chunk) : (int)blockIdx.x;
+  if (u >= nblocks) return false;
+  const int gxy = gx * gy;
+  bz = u / gxy;
+  const int r = u - bz * gxy;
+  by = r / gx;
+  bx = r - by * gx;
+  return true;
+}
+
 __global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t* __restrict__ img, int W, int H,
                                                     int istride, size_t iframe,
                                                     uint8_t* __restrict__ dst, int pstride,
-                                                    int prows, size_t dplane, int nbx, int f0) {
-  const int f = blockIdx.z + f0;
+                                                    int prows, size_t dplane, int nbx, int f0,
+                                                    int gx, int gy, int nblocks, int chunk) {
+  int bx, by, bz;
+  if (!xcd_contiguous_block(chunk, gx, gy, nblocks, bx, by, bz)) return;
+  const int f = bz + f0;
   const uint8_t* fimg = img + (size_t)f * iframe;
   // 16-pixel groups [2, ghi] are interior: all 16 pixels and the slack bytes the aligned
   // loads may touch lie inside the source row
   const int ghi = (W - 1) / 16;
-  if ((int)blockIdx.x < nbx) {
-    const int g = blockIdx.x * 64 + threadIdx.x;
-    const int py0 = (blockIdx.y * blockDim.y + threadIdx.y) * L0_ROWS;
+  if (bx < nbx) {
+    const int g = bx * 64 + threadIdx.x;
+    const int py0 = (by * (int)blockDim.y + (int)threadIdx.y) * L0_ROWS;
     if (g < 2 || g > ghi) return;
     const int P = g * 16;
     uint8_t* fdst = dst + (size_t)f * dplane + P;
@@ -135,7 +156,7 @@ __global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t* __restrict__ 
     for (int t = tid; t < rows * nb; t += 64 * (int)blockDim.y) {
       const int r = (int)(((float)t + 0.5f) * rnb);
       const int j = t - r * nb;
-      const int py = blockIdx.y * rows + r;
+      const int py = by * rows + r;
       if (py >= prows) break;
       const int c = j < 8 ? j : cr0 + (j - 8);
       const uint8_t* srow = fimg + (size_t)reflect101(py - ORBX_EDGE, H) * istride;
@@ -200,20 +221,22 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const uint8_t* __restrict__ 
                                                    const Tap* __restrict__ ytab,
                                                    const ColRec* __restrict__ colrec,
                                                    const uint16_t* __restrict__ bcols, int nbc, int nbx,
-                                                   int f0) {
+                                                   int f0, int gx, int gy, int nblocks, int chunk) {
   const int lane = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
-  const int f = blockIdx.z + f0;
+  int bx, by, bz;
+  if (!xcd_contiguous_block(chunk, gx, gy, nblocks, bx, by, bz)) return;
+  const int f = bz + f0;
   constexpr int rowsPerWave = 4 * GROUPS;
   const int rowsPerBlock = (int)blockDim.y * rowsPerWave;
-  if ((int)blockIdx.x >= nbx) {
+  if (bx >= nbx) {
     // border block: one lane per (row, border dword); taps straight from the tables,
     // source bytes straight from the (cache-resident) source plane
     const uint8_t* roi = src + (size_t)f * splane + (size_t)ORBX_EDGE * sstride + ORBX_EDGE;
     const float rnb = 1.0f / (float)nbc;
     for (int t = wave * 64 + lane; t < rowsPerBlock * nbc; t += 64 * (int)blockDim.y) {
       const int r = (int)(((float)t + 0.5f) * rnb);
-      const int py = blockIdx.y * rowsPerBlock + r;
+      const int py = by * rowsPerBlock + r;
       if (py >= prows) break;
       const int c = bcols[t - r * nbc];
       const Tap ty = ytab[py];
@@ -238,7 +261,7 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const uint8_t* __restrict__ 
   // hold all taps of the 4 pixels are fetched per source row as three dword-aligned words
   // (neighbouring lanes overlap, the vector cache serves most of it), re-based with
   // v_alignbyte, and each pixel's tap pair is picked with one v_perm_b32.
-  const int c = blockIdx.x * 64 + lane;
+  const int c = bx * 64 + lane;
   if (c * 4 >= pstride) return;
   const ColRec cr = colrec[c];
   if (!(cr.deltas & 0x8000)) return;   // border column: done by the border waves
@@ -253,7 +276,7 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const uint8_t* __restrict__ 
   }
   const uint32_t keep = cr.nvalid >= 4 ? 0xFFFFFFFFu : ((1u << (8 * cr.nvalid)) - 1u);
   uint8_t* dcol = dst + (size_t)f * dplane + 4 * c;
-  const int pyBase = (blockIdx.y * (int)blockDim.y + wave) * rowsPerWave;
+  const int pyBase = (by * (int)blockDim.y + wave) * rowsPerWave;
   if (pyBase >= prows) return;
   // the row taps of all steps first: wave-uniform, read before any store so that they can
   // come through the scalar cache
@@ -1808,9 +1831,10 @@ void launch_pyramid(const Plan& hp, const uint8_t* d_img, int istride, size_t if
   {
     const LevelDesc& L = hp.lv[0];
     const int nbx = (L.pstride / 16 + 63) / 64;
-    dim3 grid(nbx + 1, (L.prows + wpb * L0_ROWS - 1) / (wpb * L0_ROWS), nframes);
-    hipLaunchKernelGGL(k_pyr_level0, grid, blk, 0, s, d_img, hp.W, hp.H, istride, iframe,
-                       d_pyr + L.pyr_off, L.pstride, L.prows, L.pyr_plane, nbx, f0);
+    const int gx = nbx + 1, gy = (L.prows + wpb * L0_ROWS - 1) / (wpb * L0_ROWS);
+    const int nblocks = gx * gy * nframes, chunk = hp.pyr_xcd ? (nblocks + 7) / 8 : 0;
+    hipLaunchKernelGGL(k_pyr_level0, dim3(chunk ? 8 * chunk : nblocks), blk, 0, s, d_img, hp.W, hp.H, istride, iframe,
+                       d_pyr + L.pyr_off, L.pstride, L.prows, L.pyr_plane, nbx, f0, gx, gy, nblocks, chunk);
   }
   for (int l = 1; l < hp.nlevels; ++l) {
     const LevelDesc& S = hp.lv[l - 1];
@@ -1819,12 +1843,13 @@ void launch_pyramid(const Plan& hp, const uint8_t* d_img, int istride, size_t if
     // rows per wave: as many 4-row steps (up to 4) as still leave the chip about two rounds of waves
     int groups = 4;
     while (groups > 1 && (long long)nbx * ((L.prows + 4 * groups - 1) / (4 * groups)) * nframes < 16384) groups >>= 1;
-    dim3 grid(nbx + (L.n_bcols > 0 ? 1 : 0), (L.prows + 4 * wpb * groups - 1) / (4 * wpb * groups), nframes);
+    const int gx = nbx + (L.n_bcols > 0 ? 1 : 0), gy = (L.prows + 4 * wpb * groups - 1) / (4 * wpb * groups);
+    const int nblocks = gx * gy * nframes, chunk = hp.pyr_xcd ? (nblocks + 7) / 8 : 0;
     auto kern = groups == 4 ? k_pyr_resize<4> : groups == 2 ? k_pyr_resize<2> : k_pyr_resize<1>;
-    hipLaunchKernelGGL(kern, grid, blk, 0, s, d_pyr + S.pyr_off,
+    hipLaunchKernelGGL(kern, dim3(chunk ? 8 * chunk : nblocks), blk, 0, s, d_pyr + S.pyr_off,
                        S.pstride, S.pyr_plane, d_pyr + L.pyr_off, L.pstride, L.prows, L.pyr_plane,
                        L.w + 2 * ORBX_EDGE, L.xtab, L.ytab, L.colrec, L.bcols,
-                       L.n_bcols, nbx, f0);
+                       L.n_bcols, nbx, f0, gx, gy, nblocks, chunk);
   }
 }
 

@@ -102,6 +102,7 @@ struct Plan {
   const FastCell* fast_cells;   // [cells_per_frame]
   int blur_waves;        // waves per workgroup of the blur kernel, 4 or 1 (timing knob)
   int pyr_waves;         // waves per workgroup of the pyramid kernels (timing knob; results do not change)
+  int pyr_xcd;           // 1: pyramid workgroups renumbered so that neighbours share an XCD's L2 (timing knob)
   int oct_nodes_cap;     // quadtree node slots (max over levels)
   int oct_cells_max;     // max cells in one level
   int oct_keys_lds;      // keys per LDS key buffer of k_octree (0 = always use global memory)
