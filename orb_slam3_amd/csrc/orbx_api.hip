@@ -537,7 +537,7 @@ int orbx_extractor::buildPlan(int W, int H) {
     if (const char* bw = std::getenv("ORBX_BLUR_WAVES")) hp.blur_waves = std::atoi(bw) == 4 ? 4 : 1;
     hp.pyr_xcd = 1;
     if (const char* px = std::getenv("ORBX_PYR_XCD")) hp.pyr_xcd = px[0] != '0';
-    hp.pyr_waves = 2;
+    hp.pyr_waves = 1;
     if (const char* pw = std::getenv("ORBX_PYR_WAVES")) {
       const int v = std::atoi(pw);
       if (v == 1 || v == 2 || v == 4) hp.pyr_waves = v;
