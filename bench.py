@@ -609,16 +609,12 @@ def main():
     barrier()
 
     # the dominant kernel (per-cell FAST detection) timed live with HIP events on the streams its
-    # launches run on, in the same schedule as the timed loop (a batch runs as two parts)
-    det_ms, det_frames, nsample = 0.0, 0, max(3, min(args.steps, 10))
-    for _ in range(nsample):
-        step()
-        for ms, fr in ex.detect_launch_times():
-            det_ms += ms
-            det_frames += fr
-    n_launches = nsample * len(ex.detect_launch_times())
-    det_ms_per_launch = det_ms / n_launches
-    det_frames_per_launch = det_frames / n_launches
+    # launches run on: the launches of the timed loop itself (the library keeps the events of the
+    # last 32 batched calls, so reading them here puts no wait between the steps)
+    launches = ex.detect_launch_times(last_calls=min(args.steps, 32))
+    n_launches = len(launches)
+    det_ms_per_launch = sum(ms for ms, _ in launches) / n_launches
+    det_frames_per_launch = sum(fr for _, fr in launches) / n_launches
 
     # every stage serialised on one stream, whole batch per launch (each kernel alone on the chip)
     acc = {}
@@ -678,7 +674,9 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "algorithmic_bytes_per_frame": stage_bytes[dom],
                          "launch_ms": det_ms_per_launch, "frames_per_launch": det_frames_per_launch,
-                         "schedule": "timed region: a batch runs as two parts on two streams, so a detection "
+                         "launches_timed": n_launches,
+                         "schedule": "the launches of the timed steps themselves (HIP events kept per call, read "
+                                     "after the loop): a batch runs as two parts on two streams, so a detection "
                                      "launch shares the chip with the other part's blur / descriptor / pyramid "
                                      "kernels and its duration includes that sharing; 'alone' = the same kernel "
                                      "with the chip to itself (serialised stage timing, whole batch per launch)",

@@ -170,6 +170,13 @@ int orbx_stage_times(orbx_extractor* ex, float* ms, int n);
  * stream it ran on, and the frames it covered.  Waits for the call. */
 int orbx_detect_launch_times(orbx_extractor* ex, float* ms, int32_t* frames, int cap,
                              int* n_launches);
+/* The same for the last `last_calls` batched calls (at most 32 are kept), oldest
+ * first: the launches of a run of back-to-back calls, read out after the run,
+ * so that reading them does not put a wait between the calls.  Calls made in
+ * profiling mode contribute no launches.  (A measurement aid: no counterpart
+ * in the reference.) */
+int orbx_detect_launch_history(orbx_extractor* ex, int last_calls, float* ms, int32_t* frames,
+                               int cap, int* n_launches);
 
 /* ---- Hamming matching ------------------------------------------------------ */
 /* ORBmatcher::DescriptorDistance, core/lib/ORB/matcher.cc:1961-1975 (host). */

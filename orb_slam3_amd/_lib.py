@@ -82,6 +82,7 @@ SIGNATURES = {
     "orbx_set_profiling": (C.c_int, [_P, C.c_int]),
     "orbx_stage_times": (C.c_int, [_P, _f32p, C.c_int]),
     "orbx_detect_launch_times": (C.c_int, [_P, _f32p, _i32p, C.c_int, _i32p]),
+    "orbx_detect_launch_history": (C.c_int, [_P, C.c_int, _f32p, _i32p, C.c_int, _i32p]),
     "orbx_hamming": (C.c_int, [_P, _P]),
     "orbx_knn2": (C.c_int, [C.c_int, _P, C.c_int, _P, C.c_int64, _P, _P]),
     "orbx_knn2_device": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_uint32, _P, _P, _P]),

@@ -313,8 +313,13 @@ struct orbx_extractor {
   bool profiling = false;
   hipEvent_t ev[ORBX_NUM_STAGES + 1] = {};
   // normal schedule: events around the detection kernel of every part of the last call
-  hipEvent_t evDet[kMaxParts][2] = {};
-  int detFrames[kMaxParts] = {};
+  // detection-launch events of the last kDetRing batched calls (a ring: slot = call number
+  // modulo kDetRing), so that a run of back-to-back calls can be read out after it has ended
+  static const int kDetRing = 32;
+  hipEvent_t evDet[kDetRing][kMaxParts][2] = {};
+  int detFrames[kDetRing][kMaxParts] = {};
+  int detParts[kDetRing] = {};
+  long detCalls = 0;                  // batched calls so far; the current call's slot is (detCalls - 1) % kDetRing
   int lastParts = 0;
   bool evValid = false;
 
@@ -743,6 +748,8 @@ int orbx_extractor::run(const uint8_t* d_images, int istride, size_t iframe, int
   hipStream_t s = stream;
   const bool prof = profiling;
   lastParts = 0;
+  ++detCalls;
+  detParts[(detCalls - 1) % kDetRing] = 0;
   // the parts of this batch cover the same frames as those of the previous one only when the
   // batch is split the same way; anything else first waits for the previous second part
   if (pendingJoin && (prof || nframes != pendingFrames)) {
@@ -790,6 +797,7 @@ int orbx_extractor::run(const uint8_t* d_images, int istride, size_t iframe, int
       f0 += n;
     }
     lastParts = nparts;
+    detParts[(detCalls - 1) % kDetRing] = nparts;
     if (nparts > 1) {
       for (int k = 1; k < nparts; ++k) HIP_TRY(hipEventRecord(evDone[k], lane[k]));
       pendingJoin = true;
@@ -811,10 +819,11 @@ int orbx_extractor::enqueuePart(int pk, hipStream_t m, hipStream_t side, hipEven
   orbx::launch_pyramid(hp, d_images, istride, iframe, d_pyr, f0, n, m);
   if (pyrDone) HIP_TRY(hipEventRecord(pyrDone, m));
   if (blurPlace == 3) orbx::launch_blur(hp, dp, d_pyr, d_blur, f0, n, m);
-  HIP_TRY(hipEventRecord(evDet[pk][0], m));
+  const int ds = (int)((detCalls > 0 ? detCalls - 1 : 0) % kDetRing);
+  HIP_TRY(hipEventRecord(evDet[ds][pk][0], m));
   orbx::launch_fast(hp, dp, d_pyr, d_cand, d_cellCount, 0, hp.nlevels, f0, n, m);
-  HIP_TRY(hipEventRecord(evDet[pk][1], m));
-  detFrames[pk] = n;
+  HIP_TRY(hipEventRecord(evDet[ds][pk][1], m));
+  detFrames[ds][pk] = n;
   if (blurPlace == 2) orbx::launch_blur(hp, dp, d_pyr, d_blur, f0, n, m);
   if (blurPlace == 1) {
     HIP_TRY(hipEventRecord(fork, m));
@@ -915,8 +924,9 @@ int orbx_create(const orbx_params* p, orbx_extractor** out) {
   }
   for (int i = 0; i <= ORBX_NUM_STAGES; ++i)
     if (hipEventCreate(&ex->ev[i]) != hipSuccess) { orbx_destroy(ex); return ORBX_ERR_NO_DEVICE; }
-  for (int i = 0; i < 2 * orbx_extractor::kMaxParts; ++i)
-    if (hipEventCreate(&ex->evDet[i >> 1][i & 1]) != hipSuccess) { orbx_destroy(ex); return ORBX_ERR_NO_DEVICE; }
+  for (int r = 0; r < orbx_extractor::kDetRing; ++r)
+    for (int i = 0; i < 2 * orbx_extractor::kMaxParts; ++i)
+      if (hipEventCreate(&ex->evDet[r][i >> 1][i & 1]) != hipSuccess) { orbx_destroy(ex); return ORBX_ERR_NO_DEVICE; }
   bool ok = hipEventCreateWithFlags(&ex->evFork, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&ex->evStart, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&ex->evForkB, hipEventDisableTiming) == hipSuccess;
@@ -952,7 +962,9 @@ void orbx_destroy(orbx_extractor* ex) {
   (void)hipSetDevice(ex->device);
   ex->freePlan();
   for (int i = 0; i <= ORBX_NUM_STAGES; ++i) if (ex->ev[i]) (void)hipEventDestroy(ex->ev[i]);
-  for (int i = 0; i < 2 * orbx_extractor::kMaxParts; ++i) if (ex->evDet[i >> 1][i & 1]) (void)hipEventDestroy(ex->evDet[i >> 1][i & 1]);
+  for (int r = 0; r < orbx_extractor::kDetRing; ++r)
+    for (int i = 0; i < 2 * orbx_extractor::kMaxParts; ++i)
+      if (ex->evDet[r][i >> 1][i & 1]) (void)hipEventDestroy(ex->evDet[r][i >> 1][i & 1]);
   for (int k = 0; k < orbx_extractor::kLanes; ++k) {
     if (ex->lane[k]) { (void)hipStreamSynchronize(ex->lane[k]); (void)hipStreamDestroy(ex->lane[k]); }
     if (ex->evJoin[k]) (void)hipEventDestroy(ex->evJoin[k]);
@@ -1184,6 +1196,10 @@ int orbx_extract_batch(orbx_extractor* ex, int n_frames, const uint8_t* const* i
     const bool odd = k & 1;
     hipStream_t ms = odd ? ex->lane[1] : ex->stream;
     HIP_TRY(hipStreamWaitEvent(ms, ex->evIn[b], 0));
+    // (a slot of its own in the launch-event ring, reporting no launches: the groups of the host
+    // path are not the schedule those events are kept for)
+    ++ex->detCalls;
+    ex->detParts[(ex->detCalls - 1) % orbx_extractor::kDetRing] = 0;
     st = ex->enqueuePart(b, ms, ex->lane[0], ex->evForkP[b], ex->evJoinP[b], f0, m, nullptr, ex->d_img, width, frameBytes,
                          lap0, lap1);
     if (st != ORBX_OK) return st;
@@ -2133,18 +2149,31 @@ int orbx_stage_times(orbx_extractor* ex, float* ms, int n) {
   return ORBX_OK;
 }
 
-int orbx_detect_launch_times(orbx_extractor* ex, float* ms, int32_t* frames, int cap, int* n_launches) {
-  if (!ex || !ms || !frames || !n_launches || ex->lastParts <= 0 || cap < ex->lastParts) return ORBX_ERR_BAD_ARG;
+int orbx_detect_launch_history(orbx_extractor* ex, int last_calls, float* ms, int32_t* frames, int cap,
+                               int* n_launches) {
+  if (!ex || !ms || !frames || !n_launches || last_calls < 1) return ORBX_ERR_BAD_ARG;
   if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
   if (const int js_ = ex->joinParts()) return js_;
   hipError_t e = hipStreamSynchronize(ex->stream);
-  for (int k = 0; k < ex->lastParts && e == hipSuccess; ++k) {
-    e = hipEventElapsedTime(&ms[k], ex->evDet[k][0], ex->evDet[k][1]);
-    frames[k] = ex->detFrames[k];
+  const long ncalls = std::min<long>({(long)last_calls, ex->detCalls, (long)orbx_extractor::kDetRing});
+  int n = 0;
+  for (long c = ex->detCalls - ncalls; c < ex->detCalls && e == hipSuccess; ++c) {   // oldest first
+    const int ds = (int)(c % orbx_extractor::kDetRing);
+    for (int k = 0; k < ex->detParts[ds] && e == hipSuccess; ++k) {
+      if (n >= cap) return ORBX_ERR_CAPACITY;
+      e = hipEventElapsedTime(&ms[n], ex->evDet[ds][k][0], ex->evDet[ds][k][1]);
+      frames[n] = ex->detFrames[ds][k];
+      ++n;
+    }
   }
   if (e != hipSuccess) { ex->last_hip_error = e; return ORBX_ERR_HIP; }
-  *n_launches = ex->lastParts;
+  *n_launches = n;
   return ORBX_OK;
+}
+
+int orbx_detect_launch_times(orbx_extractor* ex, float* ms, int32_t* frames, int cap, int* n_launches) {
+  if (!ex || ex->lastParts <= 0 || cap < ex->lastParts) return ORBX_ERR_BAD_ARG;
+  return orbx_detect_launch_history(ex, 1, ms, frames, cap, n_launches);
 }
 
 // ---------------------------------------------------------------------------

@@ -162,13 +162,15 @@ class ORBextractor:
         return dict(zip(_lib.STAGE_NAMES, ms.tolist()))
 
     # --- stage dumps ------------------------------------------------------------------
-    def detect_launch_times(self):
-        """[(milliseconds, frames)] of the detection-kernel launches of the last batched call in the
-        normal schedule."""
-        ms = (C.c_float * 4)()
-        fr = (C.c_int32 * 4)()
+    def detect_launch_times(self, last_calls=1):
+        """[(milliseconds, frames)] of the detection-kernel launches of the last `last_calls`
+        batched calls (at most 32 are kept) in the normal schedule, oldest first."""
+        cap = 4 * 32
+        ms = (C.c_float * cap)()
+        fr = (C.c_int32 * cap)()
         n = C.c_int32()
-        check(lib().orbx_detect_launch_times(self._h, ms, fr, 4, C.byref(n)), "orbx_detect_launch_times")
+        check(lib().orbx_detect_launch_history(self._h, int(last_calls), ms, fr, cap, C.byref(n)),
+              "orbx_detect_launch_history")
         return [(float(ms[i]), int(fr[i])) for i in range(n.value)]
 
     def level_dims(self, level):

@@ -197,6 +197,27 @@ def test_device_resident_batch_matches_host_batch():
         assert mono == host[f][0] and np.array_equal(k, host[f][1]) and np.array_equal(desc, host[f][2])
 
 
+def test_detect_launch_history():
+    """The library keeps the detection-launch events of the last 32 batched calls, so the launches of
+    a run of back-to-back calls can be read after the run, oldest first, without a wait between
+    the calls (one launch per call for batches this small)."""
+    import torch
+    from tests.conftest import TORCH_DEVICE
+    frames = np.stack([orbx.textured_frame(60 + i, 376, 240) for i in range(4)])
+    ex = orbx.ORBextractor(400, 1.2, 6, 20, 7, max_batch=4)
+    d = torch.from_numpy(frames).to(TORCH_DEVICE)
+    for n in (4, 3, 2):
+        ex.extract_batch_device(d.data_ptr(), n, 376, 240, 376, (0, 0))
+    hist = ex.detect_launch_times(last_calls=3)
+    assert [fr for _, fr in hist] == [4, 3, 2]
+    assert all(ms >= 0.0 for ms, _ in hist)
+    assert [fr for _, fr in ex.detect_launch_times()] == [2]
+    assert [fr for _, fr in ex.detect_launch_times(last_calls=100)] == [4, 3, 2]
+    for _ in range(40):
+        ex.extract_batch_device(d.data_ptr(), 1, 376, 240, 376, (0, 0))
+    assert [fr for _, fr in ex.detect_launch_times(last_calls=100)] == [1] * 32
+
+
 def test_split_batch_matches_single_frames():
     """Batches of 256 frames and more are processed as two parts on two streams; every frame
     must still equal its single-frame result (checked at the part boundary and the ends)."""
