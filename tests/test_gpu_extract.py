@@ -197,6 +197,17 @@ def test_device_resident_batch_matches_host_batch():
         assert mono == host[f][0] and np.array_equal(k, host[f][1]) and np.array_equal(desc, host[f][2])
 
 
+@pytest.mark.parametrize("knob,value", [("ORBX_PYR_XCD", "0"), ("ORBX_PYR_WAVES", "2"), ("ORBX_PYR_WAVES", "4"),
+                                        ("ORBX_BLUR_WAVES", "4"), ("ORBX_SIDE_BLUR", "0"), ("ORBX_SIDE_BLUR", "2"),
+                                        ("ORBX_FAST_SINGLE_PASS", "1"), ("ORBX_OCT_KEYS_LDS", "0")])
+def test_timing_knobs_do_not_change_results(oracle, knob, value, monkeypatch):
+    """The environment knobs that exist for timing experiments (workgroup shapes and numbering, the
+    blur's place in the chain, one detection pass instead of two, quadtree keys outside LDS) select
+    other launch geometries and code paths; every stage must still equal the oracle."""
+    monkeypatch.setenv(knob, value)
+    compare_full(oracle, orbx.textured_frame(11, 640, 400), (600, 1.2, 6, 20, 7), (0, 1000))
+
+
 def test_detect_launch_history():
     """The library keeps the detection-launch events of the last 32 batched calls, so the launches of
     a run of back-to-back calls can be read after the run, oldest first, without a wait between
