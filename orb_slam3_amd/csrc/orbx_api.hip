@@ -32,6 +32,7 @@ void launch_octree(const Plan& hp, const Plan* dp, const uint32_t* d_cand, const
                    uint32_t* d_flatA, uint32_t* d_flatB, uint32_t* d_sel, int* d_selCount,
                    uint8_t* d_workspace, int l0, int l1, int f0, int nframes, hipStream_t s);
 size_t octree_lds_bytes(const Plan& hp);
+size_t fast_lds_bytes(const Plan& hp, int ts);
 void launch_assemble(const Plan& hp, const Plan* dp, const uint32_t* d_sel, const int* d_selCount,
                      int lap0, int lap1, float* d_kps, WorkItem* d_work, int* d_n, int* d_mono,
                      int f0, int nframes, hipStream_t s);
@@ -535,6 +536,19 @@ int orbx_extractor::buildPlan(int W, int H) {
   hp.fast_mm_rows = chMax + 2;
   hp.fast_qcap = std::min(512, (cwMax * chMax + 7) / 8 * 8);  // survivors queued per cell; more -> per-pixel path
   hp.fast_words = (cwMax * chMax + 31) / 32;
+  {
+    // LDS is handed out in granules of 1280 bytes (1/128 of a CU's 160 KB): what is left of the
+    // kernel's last granule goes to the survivor queue (a cell with more survivors than the queue
+    // holds is scored pixel by pixel, which costs several times as much)
+    const long gran = 1280;
+    const long bytes = (long)orbx::fast_lds_bytes(hp, hp.fast_ts);
+    const long room = (bytes + gran - 1) / gran * gran - bytes;
+    hp.fast_qcap = std::min({hp.fast_qcap + (int)(room / 2) / 8 * 8, 1024, (cwMax * chMax + 7) / 8 * 8});
+  }
+  if (const char* e = std::getenv("ORBX_FAST_QCAP")) {   // timing / test knob, results do not change
+    const int v = std::atoi(e);
+    if (v >= 8 && v <= 1024) hp.fast_qcap = std::min(v / 8 * 8, (cwMax * chMax + 7) / 8 * 8);
+  }
   {
     const char* e = std::getenv("ORBX_FAST_SINGLE_PASS");   // timing knob, results do not change
     hp.fast_two_pass = (e && e[0] == '1') ? 0 : 1;
