@@ -583,6 +583,9 @@ def main():
     torch.cuda.synchronize()
 
     ex = orbx.ORBextractor(*PARAMS, device=local_rank, max_batch=B)
+    # back-to-back steps as two independent half-batch pipelines (nothing is ordered behind the
+    # handle's stream between the steps here; the default joins the halves after every call)
+    ex.set_pipelined(True)
 
     def step():
         ex.extract_batch_device(d_imgs.data_ptr(), B, W, H, W, LAP)
@@ -721,7 +724,10 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     if stuck:
-        os._exit(0)      # a collective is still pending on a worker thread: no orderly shutdown possible
+        # a collective is still pending on a worker thread: no orderly shutdown is possible, and the
+        # run must not look like a success to whoever started it (the line above says which leg)
+        sys.stdout.flush()
+        os._exit(3)
     if world > 1:
         dist.barrier()   # the other ranks wait here while rank 0 finishes its single-rank legs
         dist.destroy_process_group()

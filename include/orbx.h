@@ -99,7 +99,8 @@ int orbx_pyramid(orbx_extractor* ex, int level, const uint8_t** padded, int* wid
  * (orbx_host_alloc, hipHostMalloc, hipHostRegister) are read and written by the
  * copy engines directly - then entries of a frame beyond its n_out are
  * unspecified; ordinary memory goes through pinned staging filled by a few
- * host threads (ORBX_HOST_THREADS, default 6). */
+ * host threads (up to 12, within OMP_NUM_THREADS and the machine's CPUs;
+ * ORBX_HOST_THREADS overrides the number). */
 int orbx_extract_batch(orbx_extractor* ex, int n_frames, const uint8_t* const* imgs, int width,
                        int height, int stride, int lap0, int lap1, orbx_keypoint* kps,
                        uint8_t* desc, int cap, int* n_out, int* mono_out);
@@ -117,6 +118,19 @@ int orbx_host_free(void* p);
 int orbx_extract_batch_device(orbx_extractor* ex, int n_frames, const uint8_t* d_imgs, int width,
                               int height, int stride, int lap0, int lap1);
 int orbx_sync(orbx_extractor* ex);
+/* A batch of 256 frames or more runs as two parts on two streams of the
+ * handle.  By default the handle's stream (orbx_stream) waits for both parts
+ * before orbx_extract_batch_device returns, so work a caller orders behind that
+ * stream - its own kernels, or overwriting d_imgs - follows the whole batch.
+ * With pipelining enabled that wait is left out between equally sized
+ * back-to-back batches (each part then follows only its own predecessor, about
+ * a tenth more frames per second): after orbx_extract_batch_device only
+ * orbx_sync, a fresh orbx_stream() / orbx_batch_results_device call, the
+ * download calls and the derived stages (stereo, grid, bag of words, matchers)
+ * cover all parts; a stream pointer fetched earlier does not.  d_imgs must then
+ * stay unchanged until one of those has been used.  No counterpart in the
+ * reference. */
+int orbx_set_pipelined(orbx_extractor* ex, int enabled);
 
 /* Device buffers of the last batched call: keypoints [n_frames][cap] (28 B),
  * descriptors [n_frames][cap][32], n and mono as int32[n_frames]. */
@@ -127,7 +141,9 @@ int orbx_batch_download(orbx_extractor* ex, int frame, orbx_keypoint* kps, uint8
                         int* n_out, int* mono_out);
 
 /* The handle's HIP stream (hipStream_t as void*), for callers that order
- * their own work against it. */
+ * their own work against it.  The pointer is constant for the handle's life;
+ * on a pipelined handle (orbx_set_pipelined) the call itself makes the stream
+ * wait for every part of the last batch, so call it again after each batch. */
 void* orbx_stream(orbx_extractor* ex);
 
 /* ---- stage dumps (parity tests; frame indexes the last batched call) ------ */
@@ -159,9 +175,12 @@ int orbx_debug_sort_records(int device_id, uint64_t* records, int n);
 #define ORBX_STAGE_BLUR 4
 #define ORBX_STAGE_DESCRIBE 5
 #define ORBX_NUM_STAGES 6
-/* When enabled, HIP events on the handle's stream bracket every stage of a
- * batched call; orbx_stage_times (after orbx_sync) returns the milliseconds
- * of the last call per stage. */
+/* When enabled, a device-resident batched call (orbx_extract_batch_device) runs
+ * its stages one after the other on the handle's stream with HIP events between
+ * them; orbx_stage_times (after orbx_sync) returns the milliseconds of the last
+ * such call per stage.  The host-pointer calls (orbx_extract,
+ * orbx_extract_batch) keep their own pipelined schedule and record no stage
+ * times: orbx_stage_times returns ORBX_ERR_BAD_ARG after them. */
 int orbx_set_profiling(orbx_extractor* ex, int enabled);
 int orbx_stage_times(orbx_extractor* ex, float* ms, int n);
 /* Detection-kernel launches of the last batched call in the normal
@@ -228,9 +247,23 @@ int orbx_top2_merge_device(const uint32_t* d_idx_parts, const uint16_t* d_dist_p
  * the same nq and their own shard; shard_offset = global index of the shard's
  * first row.  d_workspace: orbx_knn2_sharded_workspace_bytes(nranks, nq) bytes
  * of device memory, 256-byte aligned, or NULL (then the call allocates
- * stream-ordered memory itself).  Asynchronous on stream; every rank receives
- * the global result.  RCCL is taken from the copy already loaded in the process,
- * else from librccl.so.1 on the loader path; ORBX_ERR_COMM if neither exists. */
+ * stream-ordered memory itself).  Every rank receives the global result.  The
+ * call returns once the exchange has completed on stream (it reads one status
+ * word per rank from the gathered blocks); the merge that follows is
+ * asynchronous on stream.  RCCL is taken from the copy already loaded in the
+ * process, else from librccl.so.1 on the loader path; ORBX_ERR_COMM if neither
+ * exists.
+ *
+ * Failure: a rank whose own part fails (bad shard pointer, allocation failure
+ * inside its search, a workspace it cannot use) still enters the all-gather,
+ * with "no neighbour" records and its status in its block's header, and EVERY
+ * rank returns the worst status of all ranks; no rank is left waiting in the
+ * collective and the communicator stays usable.  Exceptions, which return
+ * before the collective and leave the peers waiting: a NULL or foreign
+ * communicator, RCCL missing, and failure to allocate the exchange memory when
+ * d_workspace is NULL or unusable; nq must be the same on every rank.  A
+ * non-OK status that comes from RCCL itself (ORBX_ERR_COMM) leaves the
+ * communicator unusable. */
 int orbx_knn2_sharded(void* nccl_comm, const uint8_t* d_q, int nq, const uint8_t* d_t_shard,
                       int64_t nt_shard, uint32_t shard_offset, uint32_t* d_idx, uint16_t* d_dist,
                       void* d_workspace, size_t workspace_bytes, void* stream);
@@ -297,11 +330,27 @@ int orbx_lapping_knn2(orbx_extractor* left, orbx_extractor* right, int frame, ui
  * last batched extractions on the two handles in one launch; results stay on
  * the device.  Asynchronous on the left handle's stream.
  * orbx_lapping_knn2_download fetches one frame's results in the layout of
- * orbx_lapping_knn2 (blocks; the right handle must still hold the extraction
- * the batch call saw). */
+ * orbx_lapping_knn2 (blocks; the counts it reports are those the batch call
+ * saw, kept with the left handle: the right handle may be reused or destroyed
+ * in between). */
 int orbx_lapping_knn2_batch_device(orbx_extractor* left, orbx_extractor* right, int n_frames);
 int orbx_lapping_knn2_download(orbx_extractor* left, int frame, uint32_t* idx, uint16_t* dist, int cap,
                                int* n_query, int* mono_left, int* n_train, int* mono_right);
+/* Lowe's ratio test as core/src/Frame.cc:1185 applies it to those records:
+ * matches.size() >= 2 && matches[0].distance < matches[1].distance * ratio
+ * (float distances, product and comparison in double; the reference's ratio is
+ * 0.7).  match[i] = trainIdx of the nearest neighbour when query i passes,
+ * else -1.  The generic form works on any device-resident (idx, dist) records
+ * in the layout of orbx_knn2; the batch form on the records the last
+ * orbx_lapping_knn2_batch_device call left on the left handle (frame f's
+ * verdicts at d_match + f * cap).  Asynchronous. */
+int orbx_ratio_test_device(const uint32_t* d_idx, const uint16_t* d_dist, int nq, double ratio,
+                           int32_t* d_match, void* stream);
+int orbx_lapping_ratio_test_batch_device(orbx_extractor* left, double ratio);
+int orbx_lapping_matches_device(orbx_extractor* left, int32_t** d_match, int* cap);
+/* One frame's verdicts to the host (blocks); *n_good = queries that passed. */
+int orbx_lapping_matches_download(orbx_extractor* left, int frame, int32_t* match, int cap, int* n_query,
+                                  int* n_good);
 
 /* Frame::ComputeStereoFromRGBD, core/src/Frame.cc:998-1016, for frames
  * [0, n_frames) of the last extraction + grid call on ex (the undistorted x

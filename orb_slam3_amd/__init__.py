@@ -16,7 +16,8 @@ from .extractor import ORBextractor  # noqa: F401
 from .matcher import (descriptor_distance, knn_match2, ratio_test, stereo_band_match,  # noqa: F401
                       knn_match2_sharded, shard_bounds, compute_stereo_matches,
                       compute_stereo_matches_batch, compute_stereo_from_rgbd_batch, lapping_knn_match2,
-                      lapping_knn_match2_batch, lapping_knn_download,
+                      lapping_knn_match2_batch, lapping_knn_download, lapping_ratio_test_batch,
+                      lapping_matches_download, ratio_test_device,
                       stereo_download)
 from .synth import textured_frame, right_view  # noqa: F401
 from . import grid  # noqa: F401

@@ -69,6 +69,7 @@ SIGNATURES = {
     "orbx_host_free": (C.c_int, [_P]),
     "orbx_extract_batch_device": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "orbx_sync": (C.c_int, [_P]),
+    "orbx_set_pipelined": (C.c_int, [_P, C.c_int]),
     "orbx_batch_results_device": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P),
                                             C.POINTER(_P), _i32p]),
     "orbx_batch_download": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, _i32p, _i32p]),
@@ -114,6 +115,10 @@ SIGNATURES = {
     "orbx_lapping_knn2": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, _i32p, _i32p, _i32p, _i32p]),
     "orbx_lapping_knn2_batch_device": (C.c_int, [_P, _P, C.c_int]),
     "orbx_lapping_knn2_download": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, _i32p, _i32p, _i32p, _i32p]),
+    "orbx_ratio_test_device": (C.c_int, [_P, _P, C.c_int, C.c_double, _P, _P]),
+    "orbx_lapping_ratio_test_batch_device": (C.c_int, [_P, C.c_double]),
+    "orbx_lapping_matches_device": (C.c_int, [_P, C.POINTER(_P), _i32p]),
+    "orbx_lapping_matches_download": (C.c_int, [_P, C.c_int, _P, C.c_int, _i32p, _i32p]),
     "orbx_stereo_from_rgbd_batch_device": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_float]),
     "orbx_search_by_projection_keyframe": (C.c_int, [_P, C.c_int, C.c_int, _P, _f32p, _i32p, _f32p, _P, _P, C.c_float,
                                                      C.c_int, C.c_int, _P, C.c_int, _i32p, _i32p, _i32p]),

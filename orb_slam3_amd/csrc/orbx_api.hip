@@ -26,6 +26,8 @@ void launch_pyramid(const Plan& hp, const uint8_t* d_img, int istride, size_t if
 void launch_knn2_frames(const uint8_t* descL, int capL, const int* nL, const int* monoL, const uint8_t* descR,
                         int capR, const int* nR, const int* monoR, uint32_t* idx, uint16_t* dist, int nframes,
                         hipStream_t s);
+void launch_ratio_test_frames(const uint32_t* idx, const uint16_t* dist, int cap, const int* nq, const int* mono,
+                              int nframes, double ratio, int32_t* match, hipStream_t s);
 void launch_fast(const Plan& hp, const Plan* dp, const uint8_t* d_pyr, uint32_t* d_cand,
                  int* d_cellCount, int l0, int l1, int f0, int nframes, hipStream_t s);
 void launch_octree(const Plan& hp, const Plan* dp, const uint32_t* d_cand, const int* d_cellCount,
@@ -131,7 +133,12 @@ namespace {
 class HostPool {
  public:
   explicit HostPool(int nthreads) {
-    for (int i = 0; i < nthreads; ++i) workers_.emplace_back([this] { loop(); });
+    // a thread that cannot be created (std::system_error) is done without: the pool works with
+    // those that started, in the limit with the calling thread alone
+    try {
+      for (int i = 0; i < nthreads; ++i) workers_.emplace_back([this] { loop(); });
+    } catch (...) {
+    }
   }
   ~HostPool() {
     {
@@ -272,7 +279,9 @@ struct orbx_extractor {
   uint32_t* d_lapIdx = nullptr;    // [max_batch][kp_cap][2]
   uint16_t* d_lapDist = nullptr;
   int lapFrames = 0;
-  const orbx_extractor* lapRight = nullptr;
+  int* d_lapCounts = nullptr;      // [4][max_batch]: Nleft, monoLeft, Nright, monoRight as the batch call saw them
+  int32_t* d_lapMatch = nullptr;   // [max_batch][kp_cap]: the ratio test's verdict per query (train index or -1)
+  bool lapMatchValid = false;
   // frame grid of the last grid call (undistorted keypoints + 64x48 cell CSR)
   float* d_kpsUn = nullptr;
   int* d_cellStart = nullptr;
@@ -306,6 +315,7 @@ struct orbx_extractor {
   // pipelines, each part following only its own predecessor, instead of every batch waiting for
   // the previous one's slower half.
   bool pyrWait = true;         // timing knob ORBX_PYR_WAIT: a part's pyramid waits for the previous part's
+  bool pipelined = false;      // orbx_set_pipelined: leave the join of a batch's later parts to the next call
   bool pendingJoin = false;
   int pendingFrames = 0;       // frame count of the batch whose second part is still un-joined
   int pendingParts = 0;        // and the number of its parts
@@ -393,7 +403,9 @@ void orbx_extractor::freePlan() {
   d_stBandIdx = d_stBandDist = d_stSad = nullptr; d_stURight = d_stDepth = nullptr; stereoFrames = 0;
   if (d_lapIdx) (void)hipFree(d_lapIdx);
   if (d_lapDist) (void)hipFree(d_lapDist);
-  d_lapIdx = nullptr; d_lapDist = nullptr; lapFrames = 0; lapRight = nullptr;
+  if (d_lapCounts) (void)hipFree(d_lapCounts);
+  if (d_lapMatch) (void)hipFree(d_lapMatch);
+  d_lapIdx = nullptr; d_lapDist = nullptr; d_lapCounts = nullptr; d_lapMatch = nullptr; lapFrames = 0; lapMatchValid = false;
   void* bufs[] = {d_octws, dp, d_img, d_pyr, d_blur, d_cand, d_cellCount, d_flatA, d_flatB, d_sel, d_selCount,
                   d_kps, d_desc, d_work, d_n, d_mono};
   for (void* b : bufs) if (b) (void)hipFree(b);
@@ -745,7 +757,13 @@ int orbx_extractor::ensureHostStaging(bool pageableIn, bool pageableOut) {
     const unsigned hw = std::thread::hardware_concurrency();
     if (hw >= 1) nt = std::min(nt, (int)hw);
     if (const char* e = std::getenv("ORBX_HOST_THREADS")) nt = std::min(std::max(std::atoi(e), 1), 64);
-    pool = new (std::nothrow) HostPool(nt - 1);   // the calling thread works too
+    // (thread creation can throw; nothing may cross the C ABI: without a pool the calling thread
+    // packs alone)
+    try {
+      pool = new (std::nothrow) HostPool(nt - 1);   // the calling thread works too
+    } catch (...) {
+      pool = nullptr;
+    }
   }
   return ORBX_OK;
 }
@@ -817,6 +835,13 @@ int orbx_extractor::run(const uint8_t* d_images, int istride, size_t iframe, int
       pendingJoin = true;
       pendingFrames = nframes;
       pendingParts = nparts;
+      // By default the handle's stream covers the whole batch when the call returns: a caller may
+      // have fetched orbx_stream() once and order its own work behind it.  Pipelined handles leave
+      // the join to whatever follows (see the comment at pendingJoin).
+      if (!pipelined) {
+        const int js = joinParts();
+        if (js != ORBX_OK) return js;
+      }
     }
   }
   evValid = prof;
@@ -1054,9 +1079,20 @@ int orbx_extract_batch_device(orbx_extractor* ex, int n_frames, const uint8_t* d
   return ex->run(d_imgs, stride, (size_t)stride * height, n_frames, lap0, lap1);
 }
 
+int orbx_set_pipelined(orbx_extractor* ex, int enabled) {
+  if (!ex) return ORBX_ERR_BAD_ARG;
+  if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  if (const int js_ = ex->joinParts()) return js_;
+  ex->pipelined = enabled != 0;
+  return ORBX_OK;
+}
+
 int orbx_batch_results_device(orbx_extractor* ex, orbx_keypoint** d_kps, uint8_t** d_desc,
                               int32_t** d_n, int32_t** d_mono, int* cap) {
   if (!ex || !ex->planned) return ORBX_ERR_BAD_ARG;
+  // whoever asks for the buffers is about to read them behind the handle's stream
+  if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  if (const int js_ = ex->joinParts()) return js_;
   if (d_kps) *d_kps = (orbx_keypoint*)ex->d_kps;
   if (d_desc) *d_desc = ex->d_desc;
   if (d_n) *d_n = ex->d_n;
@@ -1445,8 +1481,9 @@ int orbx_lapping_knn2(orbx_extractor* left, orbx_extractor* right, int frame, ui
 }
 
 // The same search for frames [0, n_frames) of the two last batched extractions in one launch,
-// results kept on the device (the right handle's extraction must not be redone before the download:
-// its counts are read again there).
+// results kept on the device.  The four counts per frame (Nleft, monoLeft, Nright, monoRight) are
+// copied into a buffer of the left handle in the same stream order, so that the download calls
+// read what this call saw whatever happens to the right handle afterwards.
 int orbx_lapping_knn2_batch_device(orbx_extractor* left, orbx_extractor* right, int n_frames) {
   if (!left || !right || left == right || !left->planned || !right->planned || left->device != right->device ||
       n_frames <= 0)
@@ -1462,31 +1499,41 @@ int orbx_lapping_knn2_batch_device(orbx_extractor* left, orbx_extractor* right, 
   HIP_TRY(hipEventRecord(ex->evStereo, right->stream));   // the right extraction runs on its own stream
   HIP_TRY(hipStreamWaitEvent(s, ex->evStereo, 0));
   const size_t slots = (size_t)ex->prm.max_batch * ex->hp.kp_cap;
+  const size_t B = (size_t)ex->prm.max_batch;
   if (!ex->d_lapIdx) HIP_TRY(hipMalloc((void**)&ex->d_lapIdx, slots * 8));
   if (!ex->d_lapDist) HIP_TRY(hipMalloc((void**)&ex->d_lapDist, slots * 4));
-  orbx::launch_knn2_frames(ex->d_desc, ex->hp.kp_cap, ex->d_n, ex->d_mono, right->d_desc, right->hp.kp_cap,
-                           right->d_n, right->d_mono, ex->d_lapIdx, ex->d_lapDist, n_frames, s);
+  if (!ex->d_lapCounts) HIP_TRY(hipMalloc((void**)&ex->d_lapCounts, 4 * B * 4));
+  const int* src[4] = {ex->d_n, ex->d_mono, right->d_n, right->d_mono};
+  for (int k = 0; k < 4; ++k)
+    HIP_TRY(hipMemcpyAsync(ex->d_lapCounts + k * B, src[k], (size_t)n_frames * 4, hipMemcpyDeviceToDevice, s));
+  orbx::launch_knn2_frames(ex->d_desc, ex->hp.kp_cap, ex->d_lapCounts, ex->d_lapCounts + B, right->d_desc,
+                           right->hp.kp_cap, ex->d_lapCounts + 2 * B, ex->d_lapCounts + 3 * B, ex->d_lapIdx,
+                           ex->d_lapDist, n_frames, s);
   HIP_TRY(hipGetLastError());
   ex->lapFrames = n_frames;
-  ex->lapRight = right;
+  ex->lapMatchValid = false;
+  return ORBX_OK;
+}
+
+// the four counts of one frame as the batch call saw them
+static int lapping_counts(orbx_extractor* ex, int frame, int h[4]) {
+  auto& last_hip_error = ex->last_hip_error;
+  const size_t B = (size_t)ex->prm.max_batch;
+  HIP_TRY(hipMemcpy2DAsync(h, 4, ex->d_lapCounts + frame, B * 4, 4, 4, hipMemcpyDeviceToHost, ex->stream));
+  HIP_TRY(hipStreamSynchronize(ex->stream));
   return ORBX_OK;
 }
 
 int orbx_lapping_knn2_download(orbx_extractor* left, int frame, uint32_t* idx, uint16_t* dist, int cap,
                                int* n_query, int* mono_left, int* n_train, int* mono_right) {
-  if (!left || !left->planned || !left->lapRight || frame < 0 || frame >= left->lapFrames || cap < 0)
+  if (!left || !left->planned || !left->d_lapCounts || frame < 0 || frame >= left->lapFrames || cap < 0)
     return ORBX_ERR_BAD_ARG;
   orbx_extractor* ex = left;
-  const orbx_extractor* right = ex->lapRight;
   if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
   auto& last_hip_error = ex->last_hip_error;
   hipStream_t s = ex->stream;
   int h[4] = {0, 0, 0, 0};   // Nleft, monoLeft, Nright, monoRight
-  HIP_TRY(hipMemcpyAsync(&h[0], ex->d_n + frame, 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(&h[1], ex->d_mono + frame, 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(&h[2], right->d_n + frame, 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(&h[3], right->d_mono + frame, 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
+  if (const int cs_ = lapping_counts(ex, frame, h)) return cs_;
   const int nq = h[0] - h[1], nt = h[2] - h[3];
   if (n_query) *n_query = nq;
   if (mono_left) *mono_left = h[1];
@@ -1500,6 +1547,55 @@ int orbx_lapping_knn2_download(orbx_extractor* left, int frame, uint32_t* idx, u
   HIP_TRY(hipMemcpyAsync(idx, ex->d_lapIdx + base * 2, (size_t)nq * 8, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(dist, ex->d_lapDist + base * 2, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
+  return ORBX_OK;
+}
+
+// The ratio test of core/src/Frame.cc:1185 on the records the batch call left on the device.
+int orbx_lapping_ratio_test_batch_device(orbx_extractor* left, double ratio) {
+  if (!left || !left->planned || !left->d_lapCounts || left->lapFrames <= 0 || !(ratio >= 0.0)) return ORBX_ERR_BAD_ARG;
+  orbx_extractor* ex = left;
+  if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  auto& last_hip_error = ex->last_hip_error;
+  const size_t B = (size_t)ex->prm.max_batch;
+  if (!ex->d_lapMatch) HIP_TRY(hipMalloc((void**)&ex->d_lapMatch, B * ex->hp.kp_cap * 4));
+  orbx::launch_ratio_test_frames(ex->d_lapIdx, ex->d_lapDist, ex->hp.kp_cap, ex->d_lapCounts, ex->d_lapCounts + B,
+                                 ex->lapFrames, ratio, ex->d_lapMatch, ex->stream);
+  HIP_TRY(hipGetLastError());
+  ex->lapMatchValid = true;
+  return ORBX_OK;
+}
+
+int orbx_lapping_matches_device(orbx_extractor* left, int32_t** d_match, int* cap) {
+  if (!left || !left->planned || !left->lapMatchValid || left->lapFrames <= 0) return ORBX_ERR_BAD_ARG;
+  if (d_match) *d_match = left->d_lapMatch;
+  if (cap) *cap = left->hp.kp_cap;
+  return ORBX_OK;
+}
+
+int orbx_lapping_matches_download(orbx_extractor* left, int frame, int32_t* match, int cap, int* n_query,
+                                  int* n_good) {
+  if (!left || !left->planned || !left->lapMatchValid || frame < 0 || frame >= left->lapFrames || cap < 0)
+    return ORBX_ERR_BAD_ARG;
+  orbx_extractor* ex = left;
+  if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  auto& last_hip_error = ex->last_hip_error;
+  int h[4] = {0, 0, 0, 0};
+  if (const int cs_ = lapping_counts(ex, frame, h)) return cs_;
+  const int nq = h[0] - h[1];
+  if (n_query) *n_query = nq;
+  if (n_good) *n_good = 0;
+  if (nq < 0) return ORBX_ERR_BAD_ARG;
+  if (nq > cap) return ORBX_ERR_CAPACITY;
+  if (nq == 0) return ORBX_OK;
+  if (!match) return ORBX_ERR_BAD_ARG;
+  HIP_TRY(hipMemcpyAsync(match, ex->d_lapMatch + (size_t)frame * ex->hp.kp_cap, (size_t)nq * 4, hipMemcpyDeviceToHost,
+                         ex->stream));
+  HIP_TRY(hipStreamSynchronize(ex->stream));
+  if (n_good) {
+    int g = 0;
+    for (int i = 0; i < nq; ++i) g += match[i] >= 0;
+    *n_good = g;
+  }
   return ORBX_OK;
 }
 

@@ -69,8 +69,13 @@ const Rccl& rccl() {
 }
 
 size_t align256(size_t v) { return (v + 255) / 256 * 256; }
-// one rank's block of the exchange: nq*2 indices, then nq*2 distances
-size_t block_bytes(int nq) { return align256((size_t)nq * 8) + align256((size_t)nq * 4); }
+// One rank's block of the exchange: nq*2 indices, then nq*2 distances, then a header whose first
+// word is the rank's status (0 = its records are valid, else the negated orbx_status of its
+// local search in every byte).  The status travels with the records so that a rank whose search failed still
+// takes part in the collective and every rank learns of the failure.
+size_t block_dist_off(int nq) { return align256((size_t)nq * 8); }
+size_t block_status_off(int nq) { return block_dist_off(nq) + align256((size_t)nq * 4); }
+size_t block_bytes(int nq) { return block_status_off(nq) + 256; }
 
 }  // namespace
 
@@ -115,7 +120,10 @@ size_t orbx_knn2_sharded_workspace_bytes(int nranks, int nq) {
 int orbx_knn2_sharded(void* nccl_comm, const uint8_t* d_q, int nq, const uint8_t* d_t_shard, int64_t nt_shard,
                       uint32_t shard_offset, uint32_t* d_idx, uint16_t* d_dist, void* d_workspace,
                       size_t workspace_bytes, void* stream) {
-  if (!nccl_comm || nq < 0 || nt_shard < 0) return ORBX_ERR_BAD_ARG;
+  // Failures up to here leave before any collective; they concern the communicator itself (a
+  // rank without a usable one cannot take part in anything) or nq, which the contract makes
+  // equal on every rank.
+  if (!nccl_comm || nq < 0) return ORBX_ERR_BAD_ARG;
   const Rccl& r = rccl();
   if (!r.ok) return ORBX_ERR_COMM;
   int nranks = 0, rank = -1;
@@ -123,25 +131,59 @@ int orbx_knn2_sharded(void* nccl_comm, const uint8_t* d_q, int nq, const uint8_t
       nranks < 1 || rank < 0 || rank >= nranks)
     return ORBX_ERR_COMM;
   if (nq == 0) return ORBX_OK;   // nothing to exchange either: every rank sees the same nq
-  if (!d_q || !d_idx || !d_dist) return ORBX_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
   const size_t blk = block_bytes(nq), need = (size_t)nranks * blk;
+  const size_t oDist = block_dist_off(nq), oStatus = block_status_off(nq);
+  // Everything that can differ from rank to rank is only recorded from here on: this rank enters
+  // the all-gather whatever happened, with sentinel records and its status in the block header,
+  // so that no peer is left waiting in the collective.
+  int local = ORBX_OK;
+  if (!d_q || !d_idx || !d_dist || nt_shard < 0 || (nt_shard > 0 && !d_t_shard)) local = ORBX_ERR_BAD_ARG;
   uint8_t* ws = (uint8_t*)d_workspace;
   bool own = false;
+  if (ws && (workspace_bytes < need || ((uintptr_t)ws & 255))) {
+    local = ORBX_ERR_BAD_ARG;   // unusable as given: exchange through memory of our own instead
+    ws = nullptr;
+  }
   if (!ws) {
-    if (hipMallocAsync((void**)&ws, need, s) != hipSuccess) return ORBX_ERR_HIP;
+    // without memory for the exchange this rank cannot take part: the one failure that leaves
+    // the peers waiting (they need an external timeout or an abort of the communicator)
+    if (hipMallocAsync((void**)&ws, need, s) != hipSuccess) { (void)hipGetLastError(); return ORBX_ERR_HIP; }
     own = true;
-  } else if (workspace_bytes < need || ((uintptr_t)ws & 255)) {
-    return ORBX_ERR_BAD_ARG;
   }
   // this rank's block sits where the in-place all-gather expects it
   uint8_t* mine = ws + (size_t)rank * blk;
-  const size_t oDist = align256((size_t)nq * 8);
-  int st = orbx_knn2_device(d_q, nq, d_t_shard, nt_shard, shard_offset, (uint32_t*)mine,
-                            (uint16_t*)(mine + oDist), stream);
-  // in place: this rank's block already lies at its position of the gathered array
-  if (st == ORBX_OK && r.AllGather(mine, ws, blk, kNcclUint8, nccl_comm, s) != kNcclSuccess)
-    st = ORBX_ERR_COMM;
+  if (local == ORBX_OK)
+    local = orbx_knn2_device(d_q, nq, d_t_shard, nt_shard, shard_offset, (uint32_t*)mine, (uint16_t*)(mine + oDist),
+                             stream);
+  bool hipBad = false;
+  if (local != ORBX_OK) {
+    (void)hipGetLastError();
+    // "no neighbour" records: index 0xFFFFFFFF, distance 0xFFFF
+    hipBad |= hipMemsetAsync(mine, 0xFF, oStatus, s) != hipSuccess;
+  }
+  // (the status as a byte fill: every orbx_status fits a byte, and a plain memset needs no host source)
+  hipBad |= hipMemsetAsync(mine + oStatus, -local, 4, s) != hipSuccess;
+  int st = local;
+  const bool gathered = r.AllGather(mine, ws, blk, kNcclUint8, nccl_comm, s) == kNcclSuccess;
+  if (!gathered) st = ORBX_ERR_COMM;
+  if (hipBad && st == ORBX_OK) st = ORBX_ERR_HIP;
+  if (gathered) {
+    // every rank's status word; the call waits here for the exchange (the merge below is
+    // asynchronous again)
+    int32_t codes[256];
+    const int nread = nranks < 256 ? nranks : 256;
+    if (hipMemcpy2DAsync(codes, 4, ws + oStatus, blk, 4, (size_t)nread, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) {
+      (void)hipGetLastError();
+      if (st == ORBX_OK) st = ORBX_ERR_HIP;
+    } else {
+      for (int k = 0; k < nread; ++k) {
+        const int code = codes[k] & 0xFF;
+        if (code != 0 && -code < st) st = -code;   // the worst (most negative) status wins
+      }
+    }
+  }
   if (st == ORBX_OK) {
     orbx::launch_top2_merge_strided(ws, blk, ws + oDist, blk, nranks, nq, d_idx, d_dist, s);
     if (hipGetLastError() != hipSuccess) st = ORBX_ERR_HIP;

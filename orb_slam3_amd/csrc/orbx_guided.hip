@@ -761,11 +761,9 @@ static GridView make_grid(const float* d_kpsUn, const int* d_cellStart, const in
 // the walks already run side by side there, each a chain of dependent loads, and a second launch
 // would only add its own latency; it pays once threads would have to walk several queries in turn.
 static int gather_first(int nQueries) {
-  static const int forced = [] {
-    const char* e = getenv("ORBX_GUIDED_GATHER");
-    return e ? (atoi(e) != 0 ? 1 : 0) : -1;
-  }();
-  if (forced >= 0) return forced;
+  // (read at every call, so that a test can switch it inside one process)
+  const char* e = getenv("ORBX_GUIDED_GATHER");
+  if (e && e[0]) return atoi(e) != 0 ? 1 : 0;
   return nQueries > GUIDED_THREADS ? 1 : 0;
 }
 

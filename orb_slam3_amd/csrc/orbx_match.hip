@@ -358,6 +358,27 @@ __global__ __launch_bounds__(256) void k_top2_merge(const uint8_t* __restrict__ 
   dist[2 * (size_t)qi + 1] = (uint16_t)(b1 >> 32);
 }
 
+// Lowe's ratio test as the caller of knnMatch applies it (core/src/Frame.cc:1185):
+//   matches.size() >= 2 && matches[0].distance < matches[1].distance * 0.7
+// DMatch::distance is a float holding the integer distance and the product is taken in double
+// (float * double literal).  match[i] = the nearest train index when the test holds, else -1.
+// grid (query blocks, frames): frame f's records start at f * cap * 2 and its nq[f] - mono[f]
+// first queries are tested (nq / mono null: count queries of one frame).
+__global__ __launch_bounds__(256) void k_ratio_test(const uint32_t* __restrict__ idx, const uint16_t* __restrict__ dist,
+                                                    int cap, const int* __restrict__ nq, const int* __restrict__ mono,
+                                                    int count, double ratio, int32_t* __restrict__ match) {
+  const int f = blockIdx.y;
+  const int n = nq ? nq[f] - mono[f] : count;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n || i >= cap) return;
+  const size_t o = (size_t)f * cap + i;
+  const uint2 id = ((const uint2*)idx)[o];
+  const uint32_t d = ((const uint32_t*)dist)[o];
+  const bool two = id.y != 0xFFFFFFFFu;
+  const bool good = two && (double)(float)(d & 0xFFFFu) < (double)(float)(d >> 16) * ratio;
+  match[o] = good ? (int32_t)id.x : -1;
+}
+
 // One lane per left keypoint; right keypoints are visited in ascending index,
 // so the first minimum wins as in the reference's row-bucket order.
 struct KP { float x, y, size, angle, response; int octave, class_id; };
@@ -408,6 +429,11 @@ void launch_knn2_frames(const uint8_t* descL, int capL, const int* nL, const int
   hipLaunchKernelGGL(k_knn2_mfma_frames, dim3((capL + KM_QPB - 1) / KM_QPB, nframes), dim3(256), 0, s,
                      (const uint32_t*)descL, capL, nL, monoL, (const uint32_t*)descR, capR, nR, monoR, idx, dist);
 }
+void launch_ratio_test_frames(const uint32_t* idx, const uint16_t* dist, int cap, const int* nq, const int* mono,
+                              int nframes, double ratio, int32_t* match, hipStream_t s) {
+  hipLaunchKernelGGL(k_ratio_test, dim3((cap + 255) / 256, nframes), dim3(256), 0, s, idx, dist, cap, nq, mono, 0,
+                     ratio, match);
+}
 void launch_top2_merge_strided(const uint8_t* idx_parts, size_t idx_stride, const uint8_t* dist_parts,
                                size_t dist_stride, int nparts, int nq, uint32_t* idx, uint16_t* dist,
                                hipStream_t s) {
@@ -444,9 +470,10 @@ struct KnnCut { int qblocks; long long segs; int seg_len; };
 static const size_t kPartialBytesPerQuery = 12;   // two uint32 indices + two uint16 distances
 
 // ORBX_KNN2_VALU=1 (timing knob, same results): the vector-ALU scan instead of the matrix-core one
+// (read at every call, so that a test can compare the two forms inside one process)
 static bool knn2_use_valu() {
-  static const bool v = [] { const char* e = std::getenv("ORBX_KNN2_VALU"); return e && e[0] == '1'; }();
-  return v;
+  const char* e = std::getenv("ORBX_KNN2_VALU");
+  return e && e[0] == '1';
 }
 
 static int knn2_cut(int nq, int64_t nt, size_t partial_budget, KnnCut* c) {
@@ -584,6 +611,16 @@ int orbx_top2_merge_device(const uint32_t* d_idx_parts, const uint16_t* d_dist_p
   hipLaunchKernelGGL(orbx::k_top2_merge, dim3((nq + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                      (const uint8_t*)d_idx_parts, (size_t)nq * 8, (const uint8_t*)d_dist_parts, (size_t)nq * 4,
                      nparts, nq, d_idx, d_dist);
+  return hipGetLastError() == hipSuccess ? ORBX_OK : ORBX_ERR_HIP;
+}
+
+int orbx_ratio_test_device(const uint32_t* d_idx, const uint16_t* d_dist, int nq, double ratio, int32_t* d_match,
+                           void* stream) {
+  if (nq < 0 || !(ratio >= 0.0) || (nq > 0 && (!d_idx || !d_dist || !d_match))) return ORBX_ERR_BAD_ARG;
+  if (((uintptr_t)d_idx & 7) || ((uintptr_t)d_dist & 3)) return ORBX_ERR_BAD_ARG;
+  if (nq == 0) return ORBX_OK;
+  hipLaunchKernelGGL(orbx::k_ratio_test, dim3((nq + 255) / 256, 1), dim3(256), 0, (hipStream_t)stream, d_idx, d_dist,
+                     nq, (const int*)nullptr, (const int*)nullptr, nq, ratio, d_match);
   return hipGetLastError() == hipSuccess ? ORBX_OK : ORBX_ERR_HIP;
 }
 

@@ -134,6 +134,14 @@ class ORBextractor:
     def sync(self):
         check(lib().orbx_sync(self._h), "orbx_sync")
 
+    def set_pipelined(self, on):
+        """Back-to-back equally sized batches as two independent pipelines (orbx_set_pipelined)."""
+        check(lib().orbx_set_pipelined(self._h, 1 if on else 0), "orbx_set_pipelined")
+
+    def stream(self):
+        """The handle's hipStream_t as an integer."""
+        return int(lib().orbx_stream(self._h) or 0)
+
     def download(self, frame):
         cap = self.max_keypoints()
         kps = np.zeros(cap, KEYPOINT_DTYPE)

@@ -96,6 +96,38 @@ def lapping_knn_download(ex_left, frame):
     return idx[:nq.value].copy(), dist[:nq.value].copy(), ml.value, mr.value
 
 
+def lapping_ratio_test_batch(ex_left, ratio=0.7):
+    """The ratio test of core/src/Frame.cc:1185 on the records lapping_knn_match2_batch left on the
+    device, for every frame of that batch in one launch.  Asynchronous; fetch with
+    lapping_matches_download()."""
+    check(lib().orbx_lapping_ratio_test_batch_device(ex_left._h, float(ratio)),
+          "orbx_lapping_ratio_test_batch_device")
+
+
+def lapping_matches_download(ex_left, frame):
+    """One frame's verdicts of lapping_ratio_test_batch: int32[nq], the nearest neighbour's
+    trainIdx where the query passed the ratio test, else -1."""
+    cap = ex_left.max_keypoints()
+    match = np.empty(cap, np.int32)
+    nq, ng = C.c_int32(), C.c_int32()
+    check(lib().orbx_lapping_matches_download(ex_left._h, int(frame), ptr(match), cap, C.byref(nq), C.byref(ng)),
+          "orbx_lapping_matches_download")
+    assert ng.value == int((match[:nq.value] >= 0).sum())
+    return match[:nq.value].copy()
+
+
+def ratio_test_device(idx_t, dist_t, ratio=0.7):
+    """The same test on device-resident records (torch CUDA tensors in the layout knn_match2_sharded
+    returns): int32[nq] tensor of nearest train indices, -1 where the test fails."""
+    import torch
+    nq = idx_t.shape[0]
+    out = torch.empty(nq, dtype=torch.int32, device=idx_t.device)
+    stream = torch.cuda.current_stream(idx_t.device).cuda_stream if idx_t.is_cuda else 0
+    check(lib().orbx_ratio_test_device(C.c_void_p(idx_t.data_ptr()), C.c_void_p(dist_t.data_ptr()), nq, float(ratio),
+                                       C.c_void_p(out.data_ptr()), C.c_void_p(stream)), "orbx_ratio_test_device")
+    return out
+
+
 def compute_stereo_from_rgbd_batch(ex, n_frames, d_depth_ptr, stride_floats, mbf):
     """Frame::ComputeStereoFromRGBD (core/src/Frame.cc:998-1016) for frames [0, n_frames) of the
     last extraction + grid.frame_grid_batch on ex; d_depth_ptr = device address of the float depth
@@ -227,12 +259,27 @@ def knn_match2_sharded(query_t, train_shard_t, shard_offset, group=None, comm=No
                                       C.c_void_p(ws.data_ptr()), need, C.c_void_p(stream)), "orbx_knn2_sharded")
         return idx, dst
     local_search, merge = _hooks
-    idx, dst = local_search(query_t.contiguous(), train_shard_t.contiguous(), shard_offset)
+    # Same protocol as the C entry point: a rank whose search fails still enters the exchange,
+    # with "no neighbour" records and its status beside them, and every rank raises the worst one.
+    status = 0
+    try:
+        idx, dst = local_search(query_t.contiguous(), train_shard_t.contiguous(), shard_offset)
+    except _lib.OrbxError as e:
+        status = int(e.status)
+    except Exception:
+        status = _lib.ORBX_ERR_HIP
+    if status != 0:
+        idx = torch.full((nq, 2), -1, dtype=torch.int32)
+        dst = torch.full((nq, 2), -1, dtype=torch.int16)
     if world == 1:
+        check(status, "knn_match2_sharded")
         return idx, dst
     idx_all = torch.empty((world * nq, 2), dtype=idx.dtype, device=idx.device)
     # 16-bit integers are not a collective dtype of gloo: ship the bytes
     dst_all = torch.empty((world * nq, 4), dtype=torch.uint8, device=dst.device)
+    st_all = torch.empty(world, dtype=torch.int32, device=idx.device)
     dist.all_gather_into_tensor(idx_all, idx.contiguous(), group=group)
     dist.all_gather_into_tensor(dst_all, dst.contiguous().view(torch.uint8), group=group)
+    dist.all_gather_into_tensor(st_all, torch.tensor([status], dtype=torch.int32, device=idx.device), group=group)
+    check(int(st_all.min().item()), "knn_match2_sharded (worst status over the ranks)")
     return merge(idx_all.view(world, nq, 2), dst_all.view(torch.int16).view(world, nq, 2))

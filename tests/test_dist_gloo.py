@@ -29,7 +29,7 @@ def merge_top2_numpy(idx_parts, dist_parts):
     return (best & np.uint64(0xFFFFFFFF)).astype(np.uint32), (best >> np.uint64(32)).astype(np.uint16)
 
 
-def _worker(rank, world, port, q, t, out):
+def _worker(rank, world, port, q, t, out, fail_rank=-1):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -40,6 +40,8 @@ def _worker(rank, world, port, q, t, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
 
     def local_search(qt, tt, off):
+        if rank == fail_rank:
+            raise orbx.OrbxError(-6, "injected failure of this rank's search")
         i, d = O.knn2(qt.numpy(), tt.numpy())
         i = np.where(i != 0xFFFFFFFF, i + np.uint32(off), i)
         return torch.from_numpy(i.view(np.int32).copy()), torch.from_numpy(d.view(np.int16).copy())
@@ -50,8 +52,16 @@ def _worker(rank, world, port, q, t, out):
 
     b = orbx.shard_bounds(len(t), world)
     shard = torch.from_numpy(t[b[rank]:b[rank + 1]].copy())
-    i, d = orbx.knn_match2_sharded(torch.from_numpy(q), shard, b[rank], _hooks=(local_search, merge))
-    out[rank] = (i.numpy().view(np.uint32).copy(), d.numpy().view(np.uint16).copy())
+    try:
+        i, d = orbx.knn_match2_sharded(torch.from_numpy(q), shard, b[rank], _hooks=(local_search, merge))
+        out[rank] = (i.numpy().view(np.uint32).copy(), d.numpy().view(np.uint16).copy())
+    except orbx.OrbxError as e:
+        out[rank] = ("error", int(e.status))
+    # the group is still usable after a failed search: a second, healthy exchange completes
+    if fail_rank >= 0:
+        fail_rank = -1
+        i, d = orbx.knn_match2_sharded(torch.from_numpy(q), shard, b[rank], _hooks=(local_search, merge))
+        out[(rank, "again")] = (i.numpy().view(np.uint32).copy(), d.numpy().view(np.uint16).copy())
     dist.destroy_process_group()
 
 
@@ -76,6 +86,29 @@ def test_sharded_knn_equals_unsharded(oracle, world):
         assert p.exitcode == 0
     for r in range(world):
         assert np.array_equal(out[r][0], ridx) and np.array_equal(out[r][1], rdist)
+
+
+def test_sharded_knn_failure_on_one_rank_reaches_every_rank(oracle):
+    """Rank 1's search fails: it still enters the exchange, both ranks report the error, neither
+    blocks, and the next exchange on the same group is complete and correct."""
+    import torch.multiprocessing as mp
+    rng = np.random.default_rng(7)
+    t = rng.integers(0, 256, (600, 32), dtype=np.uint8)
+    q = t[rng.integers(0, len(t), 40)].copy()
+    ridx, rdist = oracle.knn2(q, t)
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, t, out, 1)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0          # joined in time: no rank was left in the collective
+    for r in range(2):
+        assert out[r] == ("error", -6)
+        assert np.array_equal(out[(r, "again")][0], ridx) and np.array_equal(out[(r, "again")][1], rdist)
 
 
 def test_bench_spawns_ranks_itself():

@@ -1,0 +1,242 @@
+"""GPU tests of contracts around the kernels rather than of a kernel's arithmetic: the constructor
+tables as the C ABI reports them, every environment knob that selects another launch geometry or
+code path, the stream a caller orders its own work behind, the ratio test that consumes the 2-NN
+(core/src/Frame.cc:1185) and the failure path of the sharded 2-NN."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import orb_slam3_amd as orbx
+from orb_slam3_amd._lib import check, lib, ptr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("nfeatures", [1000, 1200, 1500, 2000, 5000, 10000])
+def test_constructor_tables_equal_oracle(oracle, nfeatures):
+    """ORBextractor::ORBextractor (core/lib/ORB/extractor.cc:406-463): all five tables the handle
+    reports - scale factors, their inverses, sigma^2, inverse sigma^2 (bit-identical floats) and the
+    per-level feature quotas - for the six feature counts the configurations use."""
+    ex = orbx.ORBextractor(nfeatures, 1.2, 8, 20, 7)
+    t = oracle.Extractor(nfeatures, 1.2, 8, 20, 7).tables()
+    ref = (t["scale"], t["inv"], t["sigma2"], t["inv_sigma2"], t["quota"])
+    got = (ex.GetScaleFactors(), ex.GetInverseScaleFactors(), ex.GetScaleSigmaSquares(),
+           ex.GetInverseScaleSigmaSquares(), ex.features_per_level)
+    for g, r in zip(got, ref):
+        assert g.dtype == r.dtype and g.tobytes() == r.tobytes()
+    assert int(got[4].sum()) == nfeatures
+
+
+def test_constructor_tables_other_scale(oracle):
+    ex = orbx.ORBextractor(777, 1.44, 5, 20, 7)
+    t = oracle.Extractor(777, 1.44, 5, 20, 7).tables()
+    ref = (t["scale"], t["inv"], t["sigma2"], t["inv_sigma2"], t["quota"])
+    got = (ex.GetScaleFactors(), ex.GetInverseScaleFactors(), ex.GetScaleSigmaSquares(),
+           ex.GetInverseScaleSigmaSquares(), ex.features_per_level)
+    for g, r in zip(got, ref):
+        assert g.tobytes() == r.tobytes()
+
+
+def _single_frame_results(params, images, lap):
+    ex = orbx.ORBextractor(*params)
+    out = [ex(img, None, lap) for img in images]
+    ex.close()
+    return out
+
+
+@pytest.mark.parametrize("knob,value", [("ORBX_PARTS", "1"), ("ORBX_PARTS", "3"), ("ORBX_PYR_WAIT", "0"),
+                                        ("ORBX_FAST_QCAP", "64"), ("ORBX_HOST_THREADS", "2")])
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_schedule_knobs_do_not_change_results(knob, value, pipelined, monkeypatch):
+    """The knobs that change how a batch is cut into parts, whether a part's pyramid waits for the
+    previous part's, the detection kernel's survivor queue (64 entries: many cells overflow it and
+    take the pixel-by-pixel path) and the host staging pool: a batch large enough to be split, run
+    twice back to back with different images, must give every frame its single-frame result."""
+    import torch
+    from tests.conftest import TORCH_DEVICE
+    W, H, B = 376, 240, 384
+    params = (300, 1.2, 5, 20, 7)
+    base = [orbx.textured_frame(4100 + i, W, H) for i in range(5)]
+    want = _single_frame_results(params, base, (0, 1000))
+    monkeypatch.setenv(knob, value)
+    ex = orbx.ORBextractor(*params, max_batch=B)
+    ex.set_pipelined(pipelined)
+    idx_a = [f % 5 for f in range(B)]
+    idx_b = [(f + 2) % 5 for f in range(B)]
+    da = torch.from_numpy(np.stack([base[i] for i in idx_a])).to(TORCH_DEVICE)
+    db = torch.from_numpy(np.stack([base[i] for i in idx_b])).to(TORCH_DEVICE)
+    for d in (da, db, da, db):
+        ex.extract_batch_device(d.data_ptr(), B, W, H, W, (0, 1000))
+    for f in (0, 1, 127, 128, 129, 191, 192, 255, 256, 257, 383):
+        mono, k, dsc = ex.download(f)
+        rmono, rk, rd = want[idx_b[f]]
+        assert mono == rmono and np.array_equal(k, rk) and np.array_equal(dsc, rd), f
+    if knob == "ORBX_HOST_THREADS":
+        res = ex.extract_batch(np.stack([base[i] for i in idx_a[:40]]), (0, 1000))
+        for f in range(40):
+            rmono, rk, rd = want[idx_a[f]]
+            assert res[f][0] == rmono and np.array_equal(res[f][1], rk) and np.array_equal(res[f][2], rd), f
+    ex.close()
+
+
+@pytest.mark.parametrize("gather", ["0", "1"])
+def test_guided_gather_knob(oracle, gather, monkeypatch):
+    """ORBX_GUIDED_GATHER forces the window walks of the guided matchers into (1) or out of (0) a
+    launch of their own; the assignments must not change."""
+    W, H, shift = 640, 400, 5
+    wide = orbx.textured_frame(77, W + shift, H)
+    a, b = np.ascontiguousarray(wide[:, shift:]), np.ascontiguousarray(wide[:, :W])
+    exa = orbx.ORBextractor(600, 1.2, 6, 20, 7)
+    _, ka, da = exa(a, None, (0, 0))
+    exb = orbx.ORBextractor(600, 1.2, 6, 20, 7)
+    exb(b, None, (0, 0))
+    orbx.grid.frame_grid_batch(exb, 1, None, orbx.grid.image_bounds(None, W, H))
+    rng = np.random.default_rng(3)
+    n = len(ka)
+    uv = np.stack([ka["x"] + shift + rng.uniform(-2, 2, n), ka["y"] + rng.uniform(-2, 2, n)], 1).astype(np.float32)
+    args = (exb, 0, np.ones(n, np.uint8), uv, np.full(n, 0.5, np.float32), ka["octave"], ka["angle"], da,
+            np.ones(n, np.uint8))
+    monkeypatch.delenv("ORBX_GUIDED_GATHER", raising=False)
+    ref = orbx.guided.search_by_projection_last(*args, th=15.0)
+    monkeypatch.setenv("ORBX_GUIDED_GATHER", gather)
+    got = orbx.guided.search_by_projection_last(*args, th=15.0)
+    assert got[0] == ref[0] and np.array_equal(got[1], ref[1])
+    assert ref[0] > 100
+
+
+@pytest.mark.needs_real_device
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_consumer_on_cached_stream_pointer(pipelined):
+    """A caller fetches orbx_stream() once, before a batch large enough to run as two parts, and
+    orders its own work behind that pointer right after orbx_extract_batch_device, without a
+    synchronisation: here the work overwrites the input images.  By default the handle's stream
+    covers both parts when the call returns, so the second part still reads the real images.  On a
+    pipelined handle the documented rule applies instead: the stream is fetched again after the
+    call."""
+    import torch
+    W, H, B = 376, 240, 512
+    params = (300, 1.2, 5, 20, 7)
+    base = [orbx.textured_frame(4200 + i, W, H) for i in range(4)]
+    want = _single_frame_results(params, base, (0, 1000))
+    idx = [f % 4 for f in range(B)]
+    d = torch.from_numpy(np.stack([base[i] for i in idx])).cuda()
+    ex = orbx.ORBextractor(*params, max_batch=B)
+    ex.set_pipelined(pipelined)
+    cached = torch.cuda.ExternalStream(ex.stream())
+    for rep in range(3):
+        d.copy_(torch.from_numpy(np.stack([base[i] for i in idx])), non_blocking=False)
+        torch.cuda.synchronize()
+        ex.extract_batch_device(d.data_ptr(), B, W, H, W, (0, 1000))
+        s = torch.cuda.ExternalStream(ex.stream()) if pipelined else cached
+        with torch.cuda.stream(s):
+            d.zero_()
+        s.synchronize()
+        for f in (0, 255, 256, 300, 511):
+            mono, k, dsc = ex.download(f)
+            rmono, rk, rd = want[idx[f]]
+            assert mono == rmono and np.array_equal(k, rk) and np.array_equal(dsc, rd), (rep, f)
+    ex.close()
+
+
+def test_ratio_test_device_equals_reference_rule(oracle):
+    """The caller's test on knnMatch's output, core/src/Frame.cc:1185:
+    size() >= 2 && m[0].distance < m[1].distance * 0.7 (float distances, double product)."""
+    import torch
+    from tests.conftest import TORCH_DEVICE
+    rng = np.random.default_rng(5)
+    t = rng.integers(0, 256, (700, 32), dtype=np.uint8)
+    q = t[rng.integers(0, len(t), 400)].copy()
+    flips = rng.integers(30, 110, len(q))
+    for i, nf in enumerate(flips):           # 30..109 flipped bits: both sides of the 0.7 line
+        bits = rng.choice(256, nf, replace=False)
+        for b in bits:
+            q[i, b >> 3] ^= 1 << (b & 7)
+    ridx, rdist = oracle.knn2(q, t)
+    # hand-made records on the line itself and with a missing second neighbour
+    extra_idx = np.array([[3, 9], [4, 0xFFFFFFFF], [0xFFFFFFFF, 0xFFFFFFFF], [5, 6], [7, 8], [1, 2]], np.uint32)
+    extra_dist = np.array([[7, 10], [0, 0xFFFF], [0xFFFF, 0xFFFF], [70, 100], [69, 100], [0, 0]], np.uint16)
+    idx = np.concatenate([ridx, extra_idx])
+    dist = np.concatenate([rdist, extra_dist])
+    two = idx[:, 1] != 0xFFFFFFFF
+    good = two & (dist[:, 0].astype(np.float32).astype(np.float64) < dist[:, 1].astype(np.float32).astype(np.float64) * 0.7)
+    want = np.where(good, idx[:, 0].view(np.int32), -1)
+    assert good.sum() > 50 and (~good).sum() > 50
+    assert not good[len(ridx) + 0] and not good[len(ridx) + 3] and good[len(ridx) + 4]   # 7 < 10 * 0.7 is false in double
+    got = orbx.ratio_test_device(torch.from_numpy(idx.view(np.int32)).to(TORCH_DEVICE),
+                                 torch.from_numpy(dist.view(np.int16)).to(TORCH_DEVICE), 0.7)
+    if TORCH_DEVICE == "cuda":
+        torch.cuda.synchronize()
+    assert np.array_equal(got.cpu().numpy(), want)
+    assert np.array_equal(orbx.ratio_test(idx, dist, 0.7), good)
+
+
+def test_lapping_ratio_test_batch(oracle):
+    """The same rule as a device epilogue of the batched lapping-area 2-NN, and the counts kept with
+    the left handle: the right handle is re-used for another extraction and then destroyed between
+    the batch call and the downloads."""
+    B = 3
+    frames_l = [orbx.textured_frame(131 + i, 512, 512) for i in range(B)]
+    frames_r = [np.roll(f, 6, axis=1) for f in frames_l]
+    frames_r[1] = np.zeros_like(frames_r[1])
+    exl = orbx.ORBextractor(1500, 1.2, 8, 20, 7, max_batch=B)
+    exr = orbx.ORBextractor(1500, 1.2, 8, 20, 7, max_batch=B)
+    rl = exl.extract_batch(frames_l, (100, 511))
+    rr = exr.extract_batch(frames_r, (0, 400))
+    orbx.lapping_knn_match2_batch(exl, exr, B)
+    orbx.lapping_ratio_test_batch(exl, 0.7)
+    exr.extract_batch([orbx.textured_frame(999, 512, 512)], (0, 10))   # the right handle moves on ...
+    exr.close()                                                        # ... and goes away
+    total = 0
+    for f in range(B):
+        ml, kl, dl = rl[f]
+        mr, kr, dr = rr[f]
+        idx, dist, gml, gmr = orbx.lapping_knn_download(exl, f)
+        assert (gml, gmr) == (ml, mr)
+        if dr is None:
+            assert (idx == 0xFFFFFFFF).all()
+            want = np.full(len(idx), -1, np.int32)
+        else:
+            ridx, rdist = oracle.knn2(dl[ml:], dr[mr:])
+            assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
+            good = (ridx[:, 1] != 0xFFFFFFFF) & (rdist[:, 0].astype(np.float64) < rdist[:, 1].astype(np.float64) * 0.7)
+            want = np.where(good, ridx[:, 0].view(np.int32), -1)
+        got = orbx.lapping_matches_download(exl, f)
+        assert np.array_equal(got, want), f
+        total += int((got >= 0).sum())
+    assert total > 100
+    exl.close()
+
+
+@pytest.mark.needs_real_device
+def test_sharded_knn2_local_failure_still_enters_the_exchange(oracle):
+    """A rank whose own search fails (here: a train pointer that is not 16-byte aligned) must still
+    take part in the all-gather and report the failure instead of leaving the collective to its
+    peers; the communicator stays usable, so the next call on it is complete and correct."""
+    import torch
+    from orb_slam3_amd.matcher import RcclComm
+    rng = np.random.default_rng(11)
+    t = rng.integers(0, 256, (3001, 32), dtype=np.uint8)
+    q = t[rng.integers(0, len(t), 200)].copy()
+    dev = torch.device("cuda", 0)
+    dq = torch.from_numpy(q).to(dev)
+    dt = torch.from_numpy(np.concatenate([np.zeros((1, 32), np.uint8), t])).to(dev)
+    comm = RcclComm(0)
+    ws, need = comm.workspace(len(q), dev)
+    idx = torch.empty((len(q), 2), dtype=torch.int32, device=dev)
+    dst = torch.empty((len(q), 2), dtype=torch.int16, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def call(train_ptr, workspace_ptr, workspace_bytes):
+        return lib().orbx_knn2_sharded(comm._h, C.c_void_p(dq.data_ptr()), len(q), C.c_void_p(train_ptr), len(t), 0,
+                                       C.c_void_p(idx.data_ptr()), C.c_void_p(dst.data_ptr()),
+                                       C.c_void_p(workspace_ptr), workspace_bytes, C.c_void_p(stream))
+    good_ptr = dt.data_ptr() + 32
+    assert call(good_ptr + 4, ws.data_ptr(), need) == -4          # misaligned shard: BAD_ARG, after the exchange
+    assert call(good_ptr, ws.data_ptr() + 256, need - 256) == -4  # workspace too small: exchanged through its own
+    assert call(good_ptr, ws.data_ptr(), need) == 0
+    torch.cuda.synchronize()
+    ridx, rdist = oracle.knn2(q, t)
+    assert np.array_equal(idx.cpu().numpy().view(np.uint32), ridx)
+    assert np.array_equal(dst.cpu().numpy().view(np.uint16), rdist)
+    comm.close()
