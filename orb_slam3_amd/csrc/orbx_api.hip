@@ -40,6 +40,8 @@ void launch_assemble(const Plan& hp, const Plan* dp, const uint32_t* d_sel, cons
                      int f0, int nframes, hipStream_t s);
 void launch_blur(const Plan& hp, const Plan* dp, const uint8_t* d_pyr, uint8_t* d_blur, int f0,
                  int nframes, hipStream_t s);
+void launch_describe_fused(const Plan& hp, const Plan* dp, const uint8_t* d_pyr, const WorkItem* d_work,
+                           const int* d_n, float* d_kps, uint8_t* d_desc, int f0, int nframes, hipStream_t s);
 void launch_describe(const Plan& hp, const Plan* dp, const uint8_t* d_pyr, const uint8_t* d_blur,
                      const WorkItem* d_work, const int* d_n, float* d_kps, uint8_t* d_desc,
                      int f0, int nframes, hipStream_t s);
@@ -265,6 +267,7 @@ struct orbx_extractor {
   int* d_n = nullptr;
   int* d_mono = nullptr;
   size_t pyr_bytes = 0;
+  size_t blur_bytes = 0;
   // stereo association results of this (left) handle, allocated by the first stereo call
   int* d_stBandIdx = nullptr;
   int* d_stRowStart = nullptr;   // row table of the right keypoints (CSR)
@@ -566,6 +569,10 @@ int orbx_extractor::buildPlan(int W, int H) {
     hp.fast_two_pass = (e && e[0] == '1') ? 0 : 1;
     hp.blur_waves = 1;
     if (const char* bw = std::getenv("ORBX_BLUR_WAVES")) hp.blur_waves = std::atoi(bw) == 4 ? 4 : 1;
+    // ORBX_BLUR_PLANES=1 (timing / test knob, same results): the earlier schedule with a full-plane
+    // blur launch and a descriptor kernel that reads blurred planes
+    const char* bp = std::getenv("ORBX_BLUR_PLANES");
+    hp.blur_in_describe = (bp && bp[0] == '1') ? 0 : 1;
     hp.pyr_xcd = 1;
     if (const char* px = std::getenv("ORBX_PYR_XCD")) hp.pyr_xcd = px[0] != '0';
     hp.pyr_waves = 1;
@@ -717,7 +724,9 @@ int orbx_extractor::buildPlan(int W, int H) {
   HIP_TRY(hipMemcpy(dp, &hp, sizeof(Plan), hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc((void**)&d_img, (size_t)B * W * H));
   HIP_TRY(hipMalloc((void**)&d_pyr, pyrOff + 256));  // tile loads may overrun the last row by a few bytes
-  HIP_TRY(hipMalloc((void**)&d_blur, blurOff + 256));  // window loads may overrun a row end by a few bytes
+  blur_bytes = blurOff + 256;   // window loads may overrun a row end by a few bytes
+  // blurred planes exist only for the schedule that reads them (else on demand, for the stage dump)
+  if (!hp.blur_in_describe) HIP_TRY(hipMalloc((void**)&d_blur, blur_bytes));
   HIP_TRY(hipMalloc((void**)&d_cand, (size_t)B * hp.cand_frame * 4));
   HIP_TRY(hipMalloc((void**)&d_cellCount, (size_t)B * hp.cells_per_frame * 4));
   HIP_TRY(hipMalloc((void**)&d_flatA, (size_t)B * hp.flat_frame * 4));
@@ -800,9 +809,10 @@ int orbx_extractor::run(const uint8_t* d_images, int istride, size_t iframe, int
     HIP_TRY(hipEventRecord(ev[3], s));
     orbx::launch_assemble(hp, dp, d_sel, d_selCount, lap0, lap1, d_kps, d_work, d_n, d_mono, 0, nframes, s);
     HIP_TRY(hipEventRecord(ev[4], s));
-    orbx::launch_blur(hp, dp, d_pyr, d_blur, 0, nframes, s);
+    if (!hp.blur_in_describe) orbx::launch_blur(hp, dp, d_pyr, d_blur, 0, nframes, s);
     HIP_TRY(hipEventRecord(ev[5], s));
-    orbx::launch_describe(hp, dp, d_pyr, d_blur, d_work, d_n, d_kps, d_desc, 0, nframes, s);
+    if (hp.blur_in_describe) orbx::launch_describe_fused(hp, dp, d_pyr, d_work, d_n, d_kps, d_desc, 0, nframes, s);
+    else orbx::launch_describe(hp, dp, d_pyr, d_blur, d_work, d_n, d_kps, d_desc, 0, nframes, s);
     HIP_TRY(hipEventRecord(ev[6], s));
   } else {
     // The quadtree runs one wave per (frame, level), is latency-bound and leaves most of
@@ -857,14 +867,15 @@ int orbx_extractor::enqueuePart(int pk, hipStream_t m, hipStream_t side, hipEven
                                 size_t iframe, int lap0, int lap1) {
   orbx::launch_pyramid(hp, d_images, istride, iframe, d_pyr, f0, n, m);
   if (pyrDone) HIP_TRY(hipEventRecord(pyrDone, m));
-  if (blurPlace == 3) orbx::launch_blur(hp, dp, d_pyr, d_blur, f0, n, m);
+  const bool planes = !hp.blur_in_describe;   // the full-plane blur launch exists only in that schedule
+  if (planes && blurPlace == 3) orbx::launch_blur(hp, dp, d_pyr, d_blur, f0, n, m);
   const int ds = (int)((detCalls > 0 ? detCalls - 1 : 0) % kDetRing);
   HIP_TRY(hipEventRecord(evDet[ds][pk][0], m));
   orbx::launch_fast(hp, dp, d_pyr, d_cand, d_cellCount, 0, hp.nlevels, f0, n, m);
   HIP_TRY(hipEventRecord(evDet[ds][pk][1], m));
   detFrames[ds][pk] = n;
-  if (blurPlace == 2) orbx::launch_blur(hp, dp, d_pyr, d_blur, f0, n, m);
-  if (blurPlace == 1) {
+  if (planes && blurPlace == 2) orbx::launch_blur(hp, dp, d_pyr, d_blur, f0, n, m);
+  if (planes && blurPlace == 1) {
     HIP_TRY(hipEventRecord(fork, m));
     HIP_TRY(hipStreamWaitEvent(side, fork, 0));
     orbx::launch_blur(hp, dp, d_pyr, d_blur, f0, n, side);
@@ -873,9 +884,10 @@ int orbx_extractor::enqueuePart(int pk, hipStream_t m, hipStream_t side, hipEven
   orbx::launch_octree(hp, dp, d_cand, d_cellCount, d_flatA, d_flatB, d_sel, d_selCount, d_octws, 0,
                       hp.nlevels, f0, n, m);
   orbx::launch_assemble(hp, dp, d_sel, d_selCount, lap0, lap1, d_kps, d_work, d_n, d_mono, f0, n, m);
-  if (blurPlace == 1) HIP_TRY(hipStreamWaitEvent(m, join, 0));
-  if (blurPlace == 0) orbx::launch_blur(hp, dp, d_pyr, d_blur, f0, n, m);
-  orbx::launch_describe(hp, dp, d_pyr, d_blur, d_work, d_n, d_kps, d_desc, f0, n, m);
+  if (planes && blurPlace == 1) HIP_TRY(hipStreamWaitEvent(m, join, 0));
+  if (planes && blurPlace == 0) orbx::launch_blur(hp, dp, d_pyr, d_blur, f0, n, m);
+  if (planes) orbx::launch_describe(hp, dp, d_pyr, d_blur, d_work, d_n, d_kps, d_desc, f0, n, m);
+  else orbx::launch_describe_fused(hp, dp, d_pyr, d_work, d_n, d_kps, d_desc, f0, n, m);
   return ORBX_OK;
 }
 
@@ -2219,7 +2231,18 @@ int orbx_debug_level_blurred(orbx_extractor* ex, int frame, int level, uint8_t* 
   if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
   if (const int js_ = ex->joinParts()) return js_;
   const LevelDesc& L = ex->hp.lv[level];
-  hipError_t e = hipStreamSynchronize(ex->stream);
+  hipError_t e = hipSuccess;
+  if (ex->hp.blur_in_describe) {
+    // the default schedule produces no blurred planes (the descriptor kernel blurs each keypoint's
+    // window itself): the dump runs the full-plane blur kernel on the frame's pyramid, which is
+    // still where the extraction left it
+    if (!ex->d_blur) e = hipMalloc((void**)&ex->d_blur, ex->blur_bytes);
+    if (e == hipSuccess) {
+      orbx::launch_blur(ex->hp, ex->dp, ex->d_pyr, ex->d_blur, frame, 1, ex->stream);
+      e = hipGetLastError();
+    }
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(ex->stream);
   if (e == hipSuccess)
     e = hipMemcpy2D(dst, L.w, ex->d_blur + L.blur_off + (size_t)frame * L.blur_plane, L.bstride, L.w,
                     L.h, hipMemcpyDeviceToHost);

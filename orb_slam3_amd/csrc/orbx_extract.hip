@@ -1501,9 +1501,16 @@ __global__ __launch_bounds__(256) void k_assemble(const Plan* __restrict__ plan,
       WorkItem wi;
       const LevelDesc& L = plan->lv[l];
       const int cx = (int)(key & 0xFFF) + ORBX_DET_ORG, cy = (int)((key >> 12) & 0xFFF) + ORBX_DET_ORG;
-      wi.pyr_win = L.pyr_off + (size_t)f * L.pyr_plane + (size_t)(cy + ORBX_EDGE - 15) * L.pstride +
-                   (size_t)((cx + ORBX_EDGE - 15) & ~3);
-      wi.blur_win = L.blur_off + (size_t)f * L.blur_plane + (size_t)(cy - 18) * L.bstride + (size_t)((cx - 18) & ~3);
+      if (plan->blur_in_describe) {
+        // one 43-row window of the un-blurred plane: row cy - 21, the dword that holds column cx - 21
+        wi.pyr_win = L.pyr_off + (size_t)f * L.pyr_plane + (size_t)(cy + ORBX_EDGE - 21) * L.pstride +
+                     (size_t)((cx + ORBX_EDGE - 21) & ~3);
+        wi.blur_win = 0;
+      } else {
+        wi.pyr_win = L.pyr_off + (size_t)f * L.pyr_plane + (size_t)(cy + ORBX_EDGE - 15) * L.pstride +
+                     (size_t)((cx + ORBX_EDGE - 15) & ~3);
+        wi.blur_win = L.blur_off + (size_t)f * L.blur_plane + (size_t)(cy - 18) * L.bstride + (size_t)((cx - 18) & ~3);
+      }
       wi.xy = (uint32_t)cx | ((uint32_t)cy << 16);
       wi.dst = dst;
       wi.strides = (uint32_t)L.pstride | ((uint32_t)L.bstride << 16);
@@ -1651,6 +1658,35 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
   if (x < 0) a = __fsub_rn(180.f, a);
   if (y < 0) a = __fsub_rn(360.f, a);
   return a;
+}
+
+// sin and cos of x in [0, 7) in double precision (the keypoint angle in radians): quadrant
+// reduction against pi/2 in two pieces (k * the 33-bit head is exact for k <= 4), then the
+// classic minimax polynomials for |r| <= pi/4.  Error below one unit in the last place of a
+// double, so the values rounded to float are those of a correctly rounded sin / cos except for
+// arguments within ~2^-29 (relative) of a float rounding boundary - the same guarantee the
+// math library's sincos gives, at a fifth of its instructions.
+__device__ __forceinline__ void sincos_small(double x, double& s, double& c) {
+  const double k = __builtin_rint(x * 6.36619772367581382433e-01);          // x * 2/pi
+  double r = __builtin_fma(-k, 1.57079632673412561417e+00, x);              // pi/2, first 33 bits
+  r = __builtin_fma(-k, 6.07710050650619224932e-11, r);                     // pi/2, the next 53 bits
+  const double z = r * r;
+  double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
+  ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
+  ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
+  ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
+  const double sr = __builtin_fma(z * r, ps, r);
+  double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
+  pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
+  pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
+  pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
+  const double cr = __builtin_fma(z * z, pc, __builtin_fma(z, -0.5, 1.0));
+  const int n = (int)k & 3;
+  const double s0 = (n & 1) ? cr : sr, c0 = (n & 1) ? sr : cr;
+  s = (n & 2) ? -s0 : s0;
+  c = ((n + 1) & 2) ? -c0 : c0;
 }
 
 // 16 lanes per keypoint, 4 keypoints per wave, one wave per workgroup: a one-wave workgroup with
@@ -1819,6 +1855,224 @@ __global__ __launch_bounds__(64) void k_orient_describe(const Plan* __restrict__
 }
 
 // ---------------------------------------------------------------------------
+// K5 + K6 + K7 in one kernel: orientation, the 7x7 blur of just the keypoint's sample window, and
+// the descriptor.  The descriptor only ever reads blurred pixels within 18 of its keypoint
+// (extractor.cc:110-112: pattern coordinates up to 13, rotated), and a blurred pixel is a function
+// of the 7 x 7 un-blurred pixels around it, so one 43 x 43 window of the un-blurred level holds
+// everything a keypoint needs: the 31 x 31 orientation patch and the support of the 37 x 37
+// blurred window.  The blurred planes then need not exist at all: no blur launch, no blurred
+// bytes written to or read from memory.  The arithmetic is the full-plane blur's (8.8 fixed-point
+// kernel {18,34,48,56,48,34,18}, exact 16-bit row sums, (sum + 2^15) >> 16 after the column
+// pass), applied to the padded plane, whose border is the blur's REFLECT_101 extension.
+//
+// 32 lanes per keypoint, 2 keypoints per one-wave workgroup.  Per keypoint in LDS:
+//   raw  43 rows x 12 dwords: window rows cy-21 .. cy+21, columns from the dword that holds cx-21;
+//   blw  38 rows x 10 dwords: the blurred window, rows cy-18 .. cy+19 (the last one a by-product),
+//        columns from window byte 3.
+// Passes: stage -> moments (lane j: patch row j - 15) -> blur (30 tasks of 4 columns x a band
+// of 12 or 13 rows: a lane walks down its band, forms the row sums of its 4 columns from three
+// window dwords per row and keeps them as 16-bit pairs of consecutive rows in a rolling window
+// of registers, from which two blurred rows come out of eight v_dot2 per column) -> 256 tests,
+// 8 per lane = one descriptor byte per lane.
+// ---------------------------------------------------------------------------
+#define FW_ROWS 43
+#define FW_RAW_DW (FW_ROWS * WIN_ROW_DW)      // 516 dwords
+#define FW_B_ROW_DW 10
+#define FW_B_DW (38 * FW_B_ROW_DW)            // 380 dwords
+#define FW_KP_DW (FW_RAW_DW + FW_B_DW)        // 896 dwords = 3584 bytes per keypoint
+#define FW_CHUNKS (FW_ROWS * 3)               // 16-byte chunks of the raw window
+#define FW_STAGE 5                            // chunks per lane (32 lanes per keypoint)
+
+// the 4 horizontal sums of one window row from its dwords g, g+1, g+2 (LDS)
+__device__ __forceinline__ void blur_hrow_lds(const uint32_t* rp, uint32_t (&h)[4]) {
+  const uint32_t d0 = rp[0], d1 = rp[1], d2 = rp[2];
+  const uint32_t KLO = 18u | (34u << 8) | (48u << 16) | (56u << 24);
+  const uint32_t KHI = 48u | (34u << 8) | (18u << 16);
+  h[0] = __builtin_amdgcn_udot4(d0, KLO, __builtin_amdgcn_udot4(d1, KHI, 0u, false), false);
+#pragma unroll
+  for (int c = 1; c < 4; ++c) {
+    const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, c);
+    const uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, c);
+    h[c] = __builtin_amdgcn_udot4(lo, KLO, __builtin_amdgcn_udot4(hi, KHI, 0u, false), false);
+  }
+}
+
+__global__ __launch_bounds__(64) void k_orient_blur_describe(const Plan* __restrict__ plan,
+                                                              const uint8_t* __restrict__ pyr,
+                                                              const WorkItem* __restrict__ work,
+                                                              const int* __restrict__ nOut,
+                                                              float* __restrict__ kps,
+                                                              uint8_t* __restrict__ desc, int f0,
+                                                              int nblk, int nunits, int chunk) {
+  const int unit = xcd_contiguous_unit(chunk);
+  if (unit >= nunits) return;
+  const int fr = unit / nblk;
+  const int f = fr + f0;
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 5, j32 = lane & 31;
+  const int n = nOut[f];
+  const int kbase = (unit - fr * nblk) * 2;
+  if (kbase >= n) return;
+  const int k = kbase + g;
+  const bool valid = k < n;
+  const WorkItem wi = work[(size_t)f * plan->kp_cap + (valid ? k : n - 1)];
+  const int cx = wi.xy & 0xFFFF;
+  const int ps = (int)(wi.strides & 0xFFFF);
+  __shared__ __align__(16) uint32_t sWin[2][FW_KP_DW];
+  uint32_t* raw = sWin[g];
+  uint32_t* blw = raw + FW_RAW_DW;
+  // byte of the window row at which padded column cx - 21 + EDGE sits (the window starts at the
+  // dword that holds it)
+  const int off = (cx + ORBX_EDGE - 21) & 3;
+
+  // ---- stage the un-blurred window ----------------------------------------------
+  {
+    const uint8_t* pbase = pyr + wi.pyr_win;
+    uint4 st[FW_STAGE];
+#pragma unroll
+    for (int u = 0; u < FW_STAGE; ++u) {
+      const int idx = min(j32 + 32 * u, FW_CHUNKS - 1);
+      const int r = idx / 3, c3 = idx - r * 3;
+      const U4A4 t = *(const U4A4*)(pbase + (size_t)r * ps + 16 * c3);
+      st[u] = make_uint4(t.x, t.y, t.z, t.w);
+    }
+#pragma unroll
+    for (int u = 0; u < FW_STAGE; ++u) {
+      const int idx = j32 + 32 * u;
+      if (idx < FW_CHUNKS) *(uint4*)&raw[4 * idx] = st[u];
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- IC_Angle on the un-blurred level (extractor.cc:75-99) ----------------------
+  // Lane j sums patch row v = j - 15 = window row j + 6 (lane 31 has none: its mask is empty).
+  // A row's 31 pixels u = -15 .. 15 start at window byte off + 6; eight re-based dwords hold
+  // them (plus u = 16, always masked), the row's mask keeps |u| <= umax[|v|], and two 4-way byte
+  // dot products per dword give sum(I) and sum((u + 16) I).
+  int m10, m01;
+  {
+    const int s0 = off + 6, dw0 = s0 >> 2, sh = s0 & 3;
+    const unsigned long long umaxPacked = plan->umax_packed;
+    const int v = j32 - 15;
+    const int av = v < 0 ? -v : v;
+    const int lim = av < 16 ? (int)((umaxPacked >> (4 * av)) & 15u) : -1;
+    const uint32_t lo4 = (uint32_t)(15 - lim) * 0x01010101u, hi4 = ((uint32_t)(15 + lim) * 0x01010101u) | 0x80808080u;
+    const uint32_t* rp = raw + min(j32 + 6, FW_ROWS - 1) * WIN_ROW_DW + dw0;
+    uint32_t d[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) d[i] = rp[i];
+    uint32_t sI = 0, sW = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint32_t ci = 0x03020100u + 0x04040404u * (uint32_t)i;
+      const uint32_t ok = ((ci | 0x80808080u) - lo4) & (hi4 - ci) & 0x80808080u;
+      const uint32_t mk = lim < 0 ? 0u : (ok << 1) - (ok >> 7);
+      const uint32_t x = __builtin_amdgcn_alignbyte(d[i + 1], d[i], sh) & mk;
+      const uint32_t wk = (uint32_t)(4 * i + 1) | ((uint32_t)(4 * i + 2) << 8) | ((uint32_t)(4 * i + 3) << 16) |
+                          ((uint32_t)(4 * i + 4) << 24);
+      sI = __builtin_amdgcn_udot4(x, 0x01010101u, sI, false);
+      sW = __builtin_amdgcn_udot4(x, wk, sW, false);
+    }
+    m10 = (int)sW - 16 * (int)sI;
+    m01 = v * (int)sI;
+  }
+#pragma unroll
+  for (int d = 16; d >= 1; d >>= 1) {
+    m10 += __shfl_xor(m10, d, 64);
+    m01 += __shfl_xor(m01, d, 64);
+  }
+  const float angle = fast_atan2_deg((float)m01, (float)m10);
+
+  // ---- blur of the window: blurred row rb (= window row rb + 3) from window rows rb .. rb + 6 ----
+  if (j32 < 30) {
+    const int band = j32 >= 20 ? 2 : (j32 >= 10 ? 1 : 0);
+    const int gq = j32 - 10 * band;                       // dword group: blurred columns 4 gq .. 4 gq + 3
+    const int rb0 = band == 0 ? 0 : (band == 1 ? 13 : 25);
+    const int nout = band == 0 ? 13 : 12;
+    const uint32_t* src = raw + rb0 * WIN_ROW_DW + gq;     // window row rb0, the group's first dword
+    uint32_t* dst = blw + rb0 * FW_B_ROW_DW + gq;
+    // output rows (2t, 2t+1) of the band need its input rows 2t .. 2t+7 = row pairs t .. t+3
+    uint32_t Q[4][4];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      uint32_t ha[4], hb[4];
+      blur_hrow_lds(src + (2 * m) * WIN_ROW_DW, ha);
+      blur_hrow_lds(src + (2 * m + 1) * WIN_ROW_DW, hb);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) Q[m][c] = ha[c] | (hb[c] << 16);
+    }
+    const uint32_t A0 = 18u | (34u << 16), A1 = 48u | (56u << 16), A2 = 48u | (34u << 16), A3 = 18u;
+    const uint32_t B0 = 18u << 16, B1 = 34u | (48u << 16), B2 = 56u | (48u << 16), B3 = 34u | (18u << 16);
+#pragma unroll
+    for (int tt = 0; tt < 7; ++tt) {
+      const int s = tt & 3;
+      if (2 * tt < nout) {
+        uint32_t ha[4], hb[4];
+        blur_hrow_lds(src + (2 * tt + 6) * WIN_ROW_DW, ha);
+        // the band's last odd input row lies past the window for the lowest band's last pair: its
+        // sums only feed the row below the window's last blurred row
+        blur_hrow_lds(src + min(2 * tt + 7, FW_ROWS - 1 - rb0) * WIN_ROW_DW, hb);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Q[(s + 3) & 3][c] = ha[c] | (hb[c] << 16);
+        uint32_t ra[4], rb[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const uint32_t p0 = Q[s & 3][c], p1 = Q[(s + 1) & 3][c], p2 = Q[(s + 2) & 3][c], p3 = Q[(s + 3) & 3][c];
+          ra[c] = udot2(p0, A0, udot2(p1, A1, udot2(p2, A2, udot2(p3, A3, 32768u))));
+          rb[c] = udot2(p0, B0, udot2(p1, B1, udot2(p2, B2, udot2(p3, B3, 32768u))));
+        }
+        // result byte = bits 16..23 of each sum
+        dst[(2 * tt) * FW_B_ROW_DW] = __builtin_amdgcn_perm(ra[1], ra[0], 0x0c0c0602u) |
+                                      __builtin_amdgcn_perm(ra[3], ra[2], 0x06020c0cu);
+        if (2 * tt + 1 < nout)
+          dst[(2 * tt + 1) * FW_B_ROW_DW] = __builtin_amdgcn_perm(rb[1], rb[0], 0x0c0c0602u) |
+                                            __builtin_amdgcn_perm(rb[3], rb[2], 0x06020c0cu);
+      }
+    }
+  }
+  const float factorPI = (float)(3.1415926535897932384626433832795 / 180.0);
+  const float rad = __fmul_rn(angle, factorPI);
+  double sind, cosd;
+  sincos_small((double)rad, sind, cosd);
+  const float a = (float)cosd, b = (float)sind;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- steered BRIEF on the blurred window (extractor.cc:102-145) ---------------------
+  // blurred window (row, column) = level (cy - 18 + row, cx - 18 - off + column); lane j
+  // evaluates tests 8 j .. 8 j + 7 = descriptor byte j
+  const uint8_t* bc = (const uint8_t*)blw + 18 * (4 * FW_B_ROW_DW) + (off + 18);
+  const uint4* pp = (const uint4*)(c_pattern + 32 * j32);
+  uint32_t bits = 0;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const uint4 w4 = pp[q];
+    const uint32_t ws[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t w = ws[e];   // x0, y0, x1, y1 of test 8 j + 4 q + e
+      const float x0 = (float)(int8_t)(w & 0xFF), y0 = (float)(int8_t)((w >> 8) & 0xFF);
+      const float x1 = (float)(int8_t)((w >> 16) & 0xFF), y1 = (float)(int8_t)(w >> 24);
+      // cvRound of the rotated coordinates (round half to even), then row * 40 + column; both are
+      // small integers held in floats, so the fused multiply-add is exact
+      const float r0 = rintf(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
+      const float q0 = rintf(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
+      const float r1 = rintf(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
+      const float q1 = rintf(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
+      const int t0 = bc[(int)__fmaf_rn(r0, (float)(4 * FW_B_ROW_DW), q0)];
+      const int t1 = bc[(int)__fmaf_rn(r1, (float)(4 * FW_B_ROW_DW), q1)];
+      bits |= (t0 < t1 ? 1u : 0u) << (q * 4 + e);
+    }
+  }
+  if (valid) {
+    const size_t slot = (size_t)f * plan->kp_cap + wi.dst;
+    desc[slot * 32 + j32] = (uint8_t)bits;
+    if (j32 == 0) kps[slot * 7 + 3] = angle;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // launch functions (host): frames [f0, f0 + nframes) of the batch on stream s
 // ---------------------------------------------------------------------------
 void launch_pyramid(const Plan& hp, const uint8_t* d_img, int istride, size_t iframe, uint8_t* d_pyr,
@@ -1924,6 +2178,13 @@ void launch_describe(const Plan& hp, const Plan* dp, const uint8_t* d_pyr, const
   const int nblk = (hp.kp_cap + 3) / 4, nunits = nblk * nframes, chunk = (nunits + 7) / 8;
   hipLaunchKernelGGL(k_orient_describe, dim3(8 * chunk), dim3(64), 0, s, dp, d_pyr, d_blur, d_work,
                      d_n, d_kps, d_desc, f0, nblk, nunits, chunk);
+}
+
+void launch_describe_fused(const Plan& hp, const Plan* dp, const uint8_t* d_pyr, const WorkItem* d_work,
+                           const int* d_n, float* d_kps, uint8_t* d_desc, int f0, int nframes, hipStream_t s) {
+  const int nblk = (hp.kp_cap + 1) / 2, nunits = nblk * nframes, chunk = (nunits + 7) / 8;
+  hipLaunchKernelGGL(k_orient_blur_describe, dim3(8 * chunk), dim3(64), 0, s, dp, d_pyr, d_work, d_n, d_kps, d_desc,
+                     f0, nblk, nunits, chunk);
 }
 
 int launch_debug_sort(uint64_t* d_data, int n, hipStream_t s) {

@@ -100,6 +100,10 @@ struct Plan {
   // at the lower threshold that serves both (same results; kept switchable for timing)
   int fast_two_pass;
   const FastCell* fast_cells;   // [cells_per_frame]
+  // 1: the descriptor kernel blurs each keypoint's own window in LDS and no blurred plane is
+  // produced; 0: a full-plane blur launch feeds a descriptor kernel that reads blurred planes
+  // (kept for comparison and for the blurred-plane stage dump; same results)
+  int blur_in_describe;
   int blur_waves;        // waves per workgroup of the blur kernel, 4 or 1 (timing knob)
   int pyr_waves;         // waves per workgroup of the pyramid kernels (timing knob; results do not change)
   int pyr_xcd;           // 1: pyramid workgroups renumbered so that neighbours share an XCD's L2 (timing knob)
@@ -116,8 +120,13 @@ struct Plan {
 // start (so that the kernel's first loads depend on nothing but this record) and where its
 // results go.
 struct WorkItem {
-  uint64_t pyr_win;   // byte offset in the pyramid buffer of the 31-row patch window: row cy - 15, the dword that holds column cx - 15
-  uint64_t blur_win;  // byte offset in the blurred buffer of the 37-row sample window: row cy - 18, the dword that holds column cx - 18
+  // byte offsets of the keypoint's windows.  Blur inside the descriptor kernel: pyr_win = the
+  // 43-row window of the pyramid plane (row cy - 21, the dword that holds column cx - 21),
+  // blur_win unused.  Blurred planes: pyr_win = the 31-row patch window (row cy - 15, the dword
+  // that holds column cx - 15), blur_win = the 37-row sample window in the blurred buffer (row
+  // cy - 18, the dword that holds column cx - 18).
+  uint64_t pyr_win;
+  uint64_t blur_win;
   uint32_t xy;        // x | y << 16, level coordinates
   int dst;            // output slot inside the frame
   uint32_t strides;   // row stride of the level's padded plane | row stride of its blurred plane << 16
