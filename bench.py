@@ -30,7 +30,10 @@ PARAMS = (1000, 1.2, 8, 20, 7)   # nfeatures, scaleFactor, nlevels, iniThFAST, m
 LAP = (0, 1000)                  # monocular call, core/src/Frame.cc:360
 HBM_PEAK_GBS = 8000.0
 VALU_PEAK_LANE_OPS = 256 * 64 * 2.4e9          # lane-ops/s: 256 CUs x 64 lanes x 2.4 GHz
-VALU_PEAK_WAVE_INSTS = 256 * 4 * 2.4e9 / 4     # wave instructions/s: 4 SIMDs per CU, 4 cycles each
+# wave instructions/s of the vector ALU: 4 SIMDs per CU, one wave64 instruction per 2 cycles for the
+# fast class (the guide's figure); the measured per-class rates (tools/probe/valu_rate_probe.hip) give
+# each kernel a peak of its own from its instruction mix (tools/valu_class_mix.py)
+VALU_PEAK_WAVE_INSTS = 256 * 4 * 2.4e9 / 2
 MFMA_I8_PEAK_OPS = 5.0e15                      # dense int8 matrix-core peak: twice the 2.5 PFLOP/s of bf16
 
 
@@ -56,7 +59,24 @@ def algorithmic_bytes(w, h, nlevels, scale_factor, nkp):
     return stage, total
 
 
-KERNEL_OF_STAGE = {"fast": "k_fast_cells", "blur": "k_blur"}
+KERNEL_OF_STAGE = {"fast": "k_fast_cells", "blur": "k_blur", "describe": "k_orient_blur_describe"}
+
+
+def valu_class_peak(kernel_prefix):
+    """Peak wave-instructions/s of the vector ALU for the kernel's mix of fast- and slow-class
+    instructions (static counts from the assembly, profiles/r3_valu_class_mix.json)."""
+    path = os.path.join(ROOT, "profiles", "r3_valu_class_mix.json")
+    try:
+        with open(path) as fh:
+            mix = json.load(fh)
+    except OSError:
+        return None
+    for name, r in mix.items():
+        if name.startswith(kernel_prefix):
+            return {"peak": r["peak_G_wave_insts_per_s"] * 1e9, "slow_share": r["slow_share"],
+                    "fast_ns": mix["_meta"]["fast_ns"], "slow_ns": mix["_meta"]["slow_ns"],
+                    "source": "profiles/r3_valu_class_mix.json"}
+    return None
 
 
 def pmc_counters(stage, batch, two_pass):
@@ -399,6 +419,7 @@ def kitti_bench(torch, orbx, dev, local_rank, batch=256, reps=5):
     imgs = np.stack([orbx.textured_frame(300 + i, w, h) for i in range(distinct)])
     d = torch.from_numpy(np.tile(imgs, ((batch + distinct - 1) // distinct, 1, 1))[:batch].copy()).to(dev)
     ex = orbx.ORBextractor(*params, device=local_rank, max_batch=batch)
+    ex.set_pipelined(True)
     ex.extract_batch_device(d.data_ptr(), batch, w, h, w, (0, 0))
     ex.sync()
     t0 = time.perf_counter()
@@ -410,6 +431,76 @@ def kitti_bench(torch, orbx, dev, local_rank, batch=256, reps=5):
     _, frame_bytes = algorithmic_bytes(w, h, params[2], params[1], int(round(nkp)))
     res = {"metric": "ORB frames/s @1241x376,2000kp,8lvl", "value": batch / sec, "unit": "frames/s",
            "frames_per_step": batch, "ms_per_step": sec * 1e3, "keypoints_per_frame": nkp,
+           "whole_frame_roofline_frac": batch / sec * frame_bytes / (HBM_PEAK_GBS * 1e9)}
+    ex.close()
+    return res
+
+
+def kitti_stereo_bench(torch, orbx, dev, local_rank, batch=128, reps=5):
+    """Secondary metric: 1241x376 stereo pairs/s, 2000 kp per camera: what Frame::Frame(imLeft,
+    imRight, ...) does per pair (core/src/Frame.cc:120-181) - both extractions and
+    ComputeStereoMatches (band search, L1 refinement, depth, median rule) - with the images resident
+    in HBM and everything staying on the device."""
+    import numpy as np
+    w, h, distinct = 1241, 376, 8
+    params = (2000, 1.2, 8, 20, 7)
+    lefts = [orbx.textured_frame(600 + i, w, h) for i in range(distinct)]
+    rights = [orbx.right_view(l, 600 + i) for i, l in enumerate(lefts)]
+    reps_t = (batch + distinct - 1) // distinct
+    dl = torch.from_numpy(np.tile(np.stack(lefts), (reps_t, 1, 1))[:batch].copy()).to(dev)
+    dr = torch.from_numpy(np.tile(np.stack(rights), (reps_t, 1, 1))[:batch].copy()).to(dev)
+    exl = orbx.ORBextractor(*params, device=local_rank, max_batch=batch)
+    exr = orbx.ORBextractor(*params, device=local_rank, max_batch=batch)
+    mbf, mb = 718.856 * 0.54, 0.54     # KITTI-like focal length and baseline
+
+    def run():
+        exl.extract_batch_device(dl.data_ptr(), batch, w, h, w, (0, 0))
+        exr.extract_batch_device(dr.data_ptr(), batch, w, h, w, (0, 0))
+        orbx.compute_stereo_matches_batch(exl, exr, batch, mbf, mb)
+    run()
+    exl.sync()
+    exr.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        run()
+    exl.sync()
+    exr.sync()
+    sec = (time.perf_counter() - t0) / reps
+    nmatch = float(np.mean([(orbx.stereo_download(exl, f)[1] > 0).sum() for f in range(min(batch, 8))]))
+    nkp = float(np.mean([len(exl.download(f)[1]) for f in range(4)]))
+    _, frame_bytes = algorithmic_bytes(w, h, params[2], params[1], int(round(nkp)))
+    res = {"metric": "stereo pairs/s @1241x376, 2x2000kp, extraction x2 + ComputeStereoMatches",
+           "value": batch / sec, "unit": "pairs/s", "pairs_per_step": batch, "ms_per_step": sec * 1e3,
+           "matches_per_pair": nmatch, "keypoints_per_frame": nkp,
+           "whole_frame_roofline_frac_extraction_only": 2 * batch / sec * frame_bytes / (HBM_PEAK_GBS * 1e9)}
+    exl.close()
+    exr.close()
+    return res
+
+
+def uhd_bench(torch, orbx, dev, local_rank, batch=32, reps=3):
+    """Secondary metric: frames/s at 3840x2160, 10000 kp, 8 levels (the largest configuration's
+    extraction half), batches resident in HBM.  Whole-frame fraction against the algorithmic bytes
+    of that size (138.8 MB per frame)."""
+    import numpy as np
+    w, h, distinct = 3840, 2160, 4
+    params = (10000, 1.2, 8, 20, 7)
+    imgs = np.stack([orbx.textured_frame(7000 + i, w, h) for i in range(distinct)])
+    d = torch.from_numpy(np.tile(imgs, ((batch + distinct - 1) // distinct, 1, 1))[:batch].copy()).to(dev)
+    ex = orbx.ORBextractor(*params, device=local_rank, max_batch=batch)
+    ex.set_pipelined(True)
+    ex.extract_batch_device(d.data_ptr(), batch, w, h, w, (0, 0))
+    ex.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ex.extract_batch_device(d.data_ptr(), batch, w, h, w, (0, 0))
+    ex.sync()
+    sec = (time.perf_counter() - t0) / reps
+    nkp = float(np.mean([len(ex.download(f)[1]) for f in range(2)]))
+    _, frame_bytes = algorithmic_bytes(w, h, params[2], params[1], int(round(nkp)))
+    res = {"metric": "ORB frames/s @3840x2160,10000kp,8lvl", "value": batch / sec, "unit": "frames/s",
+           "frames_per_step": batch, "ms_per_step": sec * 1e3, "keypoints_per_frame": nkp,
+           "algorithmic_bytes_per_frame": frame_bytes,
            "whole_frame_roofline_frac": batch / sec * frame_bytes / (HBM_PEAK_GBS * 1e9)}
     ex.close()
     return res
@@ -655,12 +746,18 @@ def main():
         valu = None
         if pmc and "SQ_INSTS_VALU" in pmc:
             rate = pmc["SQ_INSTS_VALU"] / (det_ms_per_launch * 1e-3)
+            cls = valu_class_peak(KERNEL_OF_STAGE[dom])
+            peak = cls["peak"] if cls else VALU_PEAK_WAVE_INSTS
             valu = {"wave_insts_per_launch": pmc["SQ_INSTS_VALU"], "insts_per_cell_wave": pmc.get("valu_per_wave"),
-                    "achieved": rate / 1e9, "peak": VALU_PEAK_WAVE_INSTS / 1e9, "unit": "G wave-insts/s",
-                    "frac": rate / VALU_PEAK_WAVE_INSTS}
+                    "achieved": rate / 1e9, "peak": peak / 1e9, "unit": "G wave-insts/s",
+                    "frac": rate / peak,
+                    "peak_is": "class-weighted: 1024 SIMDs / (share_fast * fast_ns + share_slow * slow_ns)" if cls
+                               else "one wave64 instruction per 2 cycles per SIMD",
+                    "class_mix": cls,
+                    "frac_of_2_cycle_peak": rate / VALU_PEAK_WAVE_INSTS}
             if alone:   # counters are per 512-frame launch; the serialised launch covers the whole batch
                 r_alone = pmc["SQ_INSTS_VALU"] * (B / det_frames_per_launch) / (alone["launch_ms"] * 1e-3)
-                valu["frac_alone"] = r_alone / VALU_PEAK_WAVE_INSTS
+                valu["frac_alone"] = r_alone / peak
         out = {
             "metric": "ORB frames/s @752x480,1000kp,8lvl",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -680,7 +777,7 @@ def main():
                          "launches_timed": n_launches,
                          "schedule": "the launches of the timed steps themselves (HIP events kept per call, read "
                                      "after the loop): a batch runs as two parts on two streams, so a detection "
-                                     "launch shares the chip with the other part's blur / descriptor / pyramid "
+                                     "launch shares the chip with the other part's descriptor / pyramid / quadtree "
                                      "kernels and its duration includes that sharing; 'alone' = the same kernel "
                                      "with the chip to itself (serialised stage timing, whole batch per launch)",
                          "alone": alone,
@@ -705,7 +802,9 @@ def main():
             legs += [("host_path", lambda: host_path_bench(torch, orbx, dev, local_rank, frames)),
                      ("stereo", lambda: stereo_bench(torch, orbx, dev, local_rank)),
                      ("fisheye", lambda: fisheye_bench(torch, orbx, dev, local_rank)),
-                     ("kitti", lambda: kitti_bench(torch, orbx, dev, local_rank))]
+                     ("kitti", lambda: kitti_bench(torch, orbx, dev, local_rank)),
+                     ("kitti_stereo", lambda: kitti_stereo_bench(torch, orbx, dev, local_rank)),
+                     ("uhd", lambda: uhd_bench(torch, orbx, dev, local_rank))]
         elif args.stereo:
             legs.append(("stereo", lambda: stereo_bench(torch, orbx, dev, local_rank)))
         if args.bow:
@@ -717,6 +816,10 @@ def main():
                 out[name] = fn()
             except Exception as e:
                 out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        # the interval the reference instruments (host images in -> host keypoints and descriptors
+        # out, PCIe both ways included), beside `value`, which is the device-resident rate
+        hp = out.get("host_path")
+        out["value_host_interval"] = hp["pinned"]["frames_per_s"] if isinstance(hp, dict) and "pinned" in hp else None
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
