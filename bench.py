@@ -35,6 +35,7 @@ VALU_PEAK_LANE_OPS = 256 * 64 * 2.4e9          # lane-ops/s: 256 CUs x 64 lanes 
 # each kernel a peak of its own from its instruction mix (tools/valu_class_mix.py)
 VALU_PEAK_WAVE_INSTS = 256 * 4 * 2.4e9 / 2
 MFMA_I8_PEAK_OPS = 5.0e15                      # dense int8 matrix-core peak: twice the 2.5 PFLOP/s of bf16
+MFMA_FP4_PEAK_OPS = 10.0e15                    # dense block-scaled FP4 peak (the figure with 2:1 sparsity is twice that)
 
 
 def level_sizes(w, h, nlevels, scale_factor):
@@ -163,9 +164,11 @@ def hamming_bench(torch, orbx, dev, world, rank, nq=1 << 20, nt_per_gpu=1_250_00
     1 M queries against 1.25 M train rows per GPU (10 M rows on 8 GPUs), uniform random 256-bit
     rows, everything resident in HBM.  On one rank the plain device entry point; on N ranks the
     sharded one (queries replicated, train rows sharded, one RCCL all-gather of the top-2
-    records, merge).  The scan runs on the matrix cores (a pair = a 256-deep int8 dot product,
-    512 operations), so its roofline is the dense int8 MFMA peak; the vector-ALU roof the
-    xor + popcount form is bound by (16 lane-ops per pair) is quoted beside it."""
+    records, merge).  The scan runs on the matrix cores (a pair = a 256-deep dot product of 0 / 1 by
+    +1 / -1 values, 512 operations) in the block-scaled FP4 form of the instruction, so its roofline
+    is the dense FP4 MFMA peak; the int8 form (ORBX_KNN2_I8=1) is priced against the int8 peak, and
+    the vector-ALU roof the xor + popcount form (ORBX_KNN2_VALU=1) is bound by (16 lane-ops per
+    pair) is quoted beside them."""
     import ctypes as C
     from orb_slam3_amd._lib import lib, check
     g = torch.Generator(device=dev).manual_seed(1234)
@@ -205,10 +208,18 @@ def hamming_bench(torch, orbx, dev, world, rank, nq=1 << 20, nt_per_gpu=1_250_00
     out = {"metric": "Hamming pairs/s (brute-force 2-NN, train rows sharded over the GPUs)",
            "value": pairs, "unit": "pairs/s", "queries": nq, "train_rows_total": nt_per_gpu * world,
            "train_rows_per_gpu": nt_per_gpu, "ms": sec * 1e3, "n_gpus": world,
-           "roofline": {"bound": "mfma", "achieved": pairs * 512 / 1e12, "peak": MFMA_I8_PEAK_OPS * world / 1e12,
-                        "unit": "TOP/s (int8)", "frac": pairs * 512 / (MFMA_I8_PEAK_OPS * world),
-                        "kernel": "k_knn2_mfma (v_mfma_i32_32x32x32_i8)",
+           "roofline": {"bound": "mfma", "achieved": pairs * 512 / 1e12, "peak": MFMA_FP4_PEAK_OPS * world / 1e12,
+                        "unit": "TOP/s (FP4)", "frac": pairs * 512 / (MFMA_FP4_PEAK_OPS * world),
+                        "kernel": "k_knn2_fp4 (v_mfma_scale_f32_32x32x64_f8f6f4, both operands e2m1, unit scales)",
+                        "frac_of_measured_instruction_rate": pairs / (17.3e12 * world),
+                        "measured_instruction_rate": "17.3 T pairs/s: back-to-back instructions, two waves per SIMD "
+                                                     "(tools/probe/fp4_hamming_probe.hip, profiles/r3_fp4_hamming_probe.txt)",
+                        "times_the_int8_peak": pairs * 512 / (MFMA_I8_PEAK_OPS * world),
                         "times_the_vector_alu_roof": pairs * 16 / (VALU_PEAK_LANE_OPS * world)}}
+    if os.environ.get("ORBX_KNN2_I8") == "1":
+        out["roofline"] = {"bound": "mfma", "achieved": pairs * 512 / 1e12, "peak": MFMA_I8_PEAK_OPS * world / 1e12,
+                           "unit": "TOP/s (int8)", "frac": pairs * 512 / (MFMA_I8_PEAK_OPS * world),
+                           "kernel": "k_knn2_mfma (v_mfma_i32_32x32x32_i8)"}
     if os.environ.get("ORBX_KNN2_VALU") == "1":
         out["roofline"] = {"bound": "valu", "achieved": pairs * 16 / 1e12, "peak": VALU_PEAK_LANE_OPS * world / 1e12,
                            "unit": "T lane-ops/s", "frac": pairs * 16 / (VALU_PEAK_LANE_OPS * world),

@@ -27,6 +27,9 @@ void keep_pool_memory(int device);   // orbx_api.hip
 #define KNN_BLOCK 256
 #define KNN_IDX_BITS 22    // train rows per scan segment <= 2^22
 #define KNN_ROWS 4          // train rows per step of the scan
+#ifndef KNN_WANT_WGS
+#define KNN_WANT_WGS 8192  // workgroups a matrix-core scan is cut into at least (query blocks x train segments)
+#endif
 
 // Candidates are ranked by the 32-bit word (distance << 22 | local train
 // index): its unsigned order is exactly (distance, index) ascending, the
@@ -329,6 +332,211 @@ __global__ __launch_bounds__(256) void k_knn2_mfma_frames(const uint32_t* __rest
                  max(nt, 0), 0u, out_idx + (size_t)f * capL * 2, out_dist + (size_t)f * capL * 2, sA);
 }
 
+// ---------------------------------------------------------------------------
+// The same scan on the block-scaled FP4 form of the matrix instruction
+// (v_mfma_scale_f32_32x32x64_f8f6f4 with both operands e2m1 and both scales 2^0): 64 bits of the
+// descriptors per instruction instead of 32, in about the same cycles, so twice the pairs per
+// clock of the int8 form.  A train bit is the nibble 0x2 (1.0) or 0x0, a query bit the nibble
+// 0x2 (+1.0, bit clear) or 0xA (-1.0, bit set); products and sums are small integers, exact in
+// the f32 accumulators.  Step s of a pair's four instructions takes words 2s and 2s+1 of the
+// descriptors, lane half h word 2s+h, whose 32 bits become the 32 nibbles of the lane's four
+// operand dwords: dword d holds bits d, d+4, .. d+28 (the slot order inside an instruction is
+// free as long as both operands use the same one), which is (word << 1 >> d) & 0x22222222 - one
+// shift and one and per eight bits.  A train tile of 32 rows is 4 KB in LDS (step, half, row:
+// a wave's 16-byte reads are contiguous); everything else - query tiles resident in registers,
+// two train tiles per barrier, per-lane top-2 upkeep gated by one compare per tile - is the
+// int8 kernel's.
+// ---------------------------------------------------------------------------
+#ifndef KF_NQT
+#define KF_NQT 2                              // query tiles of 32 per wave
+#endif
+#define KF_QPB (KM_WAVES * KF_NQT * 32)       // queries per workgroup
+#ifndef KF_SUB
+#define KF_SUB 2                              // train tiles of 32 rows per stage
+#endif
+#define KF_TILE 4096                          // bytes of one train tile in LDS
+typedef int km_v8i __attribute__((ext_vector_type(8)));
+typedef float km_v16f __attribute__((ext_vector_type(16)));
+#define KF_SCALE_ONE 0x7f7f7f7f               // E8M0 scale bytes: 2^(127 - 127)
+#define KF_BIAS 512.0f                        // start value of the accumulators (see the scan)
+
+// the 32 bits of a word as 32 e2m1 nibbles, 1.0 where the bit is set
+__device__ __forceinline__ km_v4i bits_to_fp4(uint32_t w) {
+  km_v4i r;
+  r.x = (int)((w << 1) & 0x22222222u);
+  r.y = (int)(w & 0x22222222u);
+  r.z = (int)((w >> 1) & 0x22222222u);
+  r.w = (int)((w >> 2) & 0x22222222u);
+  return r;
+}
+// 0 / 1.0 nibbles -> +1.0 / -1.0 nibbles
+__device__ __forceinline__ int fp4_pm1(int t) { return (int)(0x22222222u | ((uint32_t)t << 2)); }
+__device__ __forceinline__ km_v8i fp4_operand(km_v4i v) {   // the instruction reads the first four dwords
+  km_v8i r = {v.x, v.y, v.z, v.w, 0, 0, 0, 0};
+  return r;
+}
+
+__device__ __forceinline__ void knn2_fp4_scan(const uint32_t* __restrict__ q, int nq, int qblock,
+                                              const uint32_t* __restrict__ tp, int len, uint32_t idx_base,
+                                              uint32_t* __restrict__ out_idx, uint16_t* __restrict__ out_dist,
+                                              uint8_t (*sA)[KF_SUB * KF_TILE]) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  // ---- the wave's queries as B operands (+1 / -1), and their popcounts --------
+  km_v4i bq[KF_NQT][4];
+  float qpopb[KF_NQT];   // popcount - bias: distance = result + popcount - bias
+#pragma unroll
+  for (int qt = 0; qt < KF_NQT; ++qt) {
+    const int qi = qblock * KF_QPB + (wave * KF_NQT + qt) * 32 + r;
+    const uint4* qp = (const uint4*)(q + (size_t)min(qi, nq - 1) * 8);
+    const uint4 a = qp[0], b = qp[1];
+    const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    int pc = 0;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) pc += __builtin_popcount(w[s]);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const km_v4i e = bits_to_fp4(h ? w[2 * s + 1] : w[2 * s]);
+      bq[qt][s].x = fp4_pm1(e.x); bq[qt][s].y = fp4_pm1(e.y); bq[qt][s].z = fp4_pm1(e.z); bq[qt][s].w = fp4_pm1(e.w);
+    }
+    qpopb[qt] = (float)pc - KF_BIAS;
+  }
+  uint32_t k0[KF_NQT], k1[KF_NQT];
+  // The accumulators start at KF_BIAS instead of zero, so every result (bias + product, product in
+  // [-256, 256]) is a positive float and its bit pattern orders like its value: the smallest of a
+  // lane's 16 results comes out of integer min3 instructions (the float ones first have to quiet
+  // possible NaNs).  A row can enter when its result is below thd = bias + second-best distance -
+  // popcount, kept as a bit pattern too.
+  uint32_t thd[KF_NQT];
+#pragma unroll
+  for (int qt = 0; qt < KF_NQT; ++qt) { k0[qt] = 0xFFFFFFFFu; k1[qt] = 0xFFFFFFFFu; thd[qt] = __float_as_uint(KF_BIAS + 1024.f); }
+  km_v16f zero;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) zero[i] = KF_BIAS;
+
+  // ---- train tiles, KF_SUB of them per stage (one workgroup barrier per stage) ------
+  // staging: this thread's row of a tile and word of the row; word sw = 2 s + h goes to the
+  // operand slot of step s, half h
+  const int srow = tid & 31, sw = tid >> 5;
+  const int ntiles = (len + 31) >> 5;
+  const int nstages = (ntiles + KF_SUB - 1) / KF_SUB;
+  uint32_t pre[KF_SUB];
+  auto fetch = [&](int stg) {
+#pragma unroll
+    for (int u = 0; u < KF_SUB; ++u) {
+      const int row = (stg * KF_SUB + u) * 32 + srow;
+      pre[u] = row < len ? tp[(size_t)row * 8 + sw] : 0u;
+    }
+  };
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < KF_SUB; ++u) *(km_v4i*)&sA[buf][u * KF_TILE + (sw * 32 + srow) * 16] = bits_to_fp4(pre[u]);
+  };
+  if (nstages > 0) { fetch(0); stage(0); }
+  __syncthreads();
+  for (int stg = 0; stg < nstages; ++stg) {
+    const int cur = stg & 1;
+    if (stg + 1 < nstages) fetch(stg + 1);
+#pragma unroll
+    for (int sub = 0; sub < KF_SUB; ++sub) {
+      const int tile = stg * KF_SUB + sub;
+      const uint8_t* tileA = &sA[cur][sub * KF_TILE];
+      km_v16f acc[KF_NQT];
+      km_v4i a[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[u] = *(const km_v4i*)&tileA[((u * 2 + h) * 32 + r) * 16];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int qt = 0; qt < KF_NQT; ++qt)
+          acc[qt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp4_operand(a[u]), fp4_operand(bq[qt][u]),
+                                                                    u == 0 ? zero : acc[qt], 4, 4, 0, KF_SCALE_ONE, 0,
+                                                                    KF_SCALE_ONE);
+      // can any of the lane's 16 rows enter?  (smallest product against the threshold; rows past
+      // the segment's end are zeros in LDS and are refused again where the keys are built)
+      bool any[KF_NQT];
+      bool anyAll = false;
+#pragma unroll
+      for (int qt = 0; qt < KF_NQT; ++qt) {
+        uint32_t mn = __float_as_uint(acc[qt][0]);
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mn = min(mn, __float_as_uint(acc[qt][i]));
+        any[qt] = mn < thd[qt];
+        anyAll |= any[qt];
+      }
+      if (__any(anyAll)) {
+        // (an empty asm statement cannot be executed speculatively: without it the compiler could
+        // turn this rarely taken block into straight-line code with selects)
+        asm volatile("" ::: "memory");
+        const int rowBase = tile * 32 + 4 * h;
+        const bool whole = tile * 32 + 32 <= len;     // every row of the tile exists (all but the last tile)
+#pragma unroll
+        for (int qt = 0; qt < KF_NQT; ++qt) {
+          if (!__any(any[qt])) continue;               // wave-uniform: only the query tile that has a candidate
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int row = rowBase + (i & 3) + 8 * (i >> 2);
+            const uint32_t dist = (uint32_t)(int)(qpopb[qt] + acc[qt][i]);
+            const uint32_t key = (whole || row < len) ? ((dist << KNN_IDX_BITS) | (uint32_t)row) : 0xFFFFFFFFu;
+            const uint32_t hi = max(k0[qt], key);
+            k0[qt] = min(k0[qt], key);
+            k1[qt] = min(k1[qt], hi);
+          }
+          // (an empty second slot gives a distance field of 1023: above every result)
+          thd[qt] = __float_as_uint((float)(int)(k1[qt] >> KNN_IDX_BITS) - qpopb[qt]);
+        }
+      }
+    }
+    if (stg + 1 < nstages) stage(cur ^ 1);
+    __syncthreads();
+  }
+  // ---- the two lanes of a query merge their pairs ------------------------------
+#pragma unroll
+  for (int qt = 0; qt < KF_NQT; ++qt) {
+    const uint32_t p0 = __shfl_xor(k0[qt], 32, 64), p1 = __shfl_xor(k1[qt], 32, 64);
+    const uint32_t m0 = min(k0[qt], p0);
+    const uint32_t m1 = min(max(k0[qt], p0), min(k1[qt], p1));
+    const int qi = qblock * KF_QPB + (wave * KF_NQT + qt) * 32 + r;
+    if (h == 0 && qi < nq) {
+      const size_t o = (size_t)qi * 2;
+      const uint32_t mask = (1u << KNN_IDX_BITS) - 1u;
+      out_idx[o] = m0 == 0xFFFFFFFFu ? 0xFFFFFFFFu : idx_base + (m0 & mask);
+      out_idx[o + 1] = m1 == 0xFFFFFFFFu ? 0xFFFFFFFFu : idx_base + (m1 & mask);
+      out_dist[o] = m0 == 0xFFFFFFFFu ? (uint16_t)0xFFFF : (uint16_t)(m0 >> KNN_IDX_BITS);
+      out_dist[o + 1] = m1 == 0xFFFFFFFFu ? (uint16_t)0xFFFF : (uint16_t)(m1 >> KNN_IDX_BITS);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_knn2_fp4(const uint32_t* __restrict__ q, int nq,
+                                                  const uint32_t* __restrict__ t, long long nt,
+                                                  int seg_len, uint32_t index_offset,
+                                                  uint32_t* __restrict__ out_idx,
+                                                  uint16_t* __restrict__ out_dist) {
+  __shared__ __align__(16) uint8_t sA[2][KF_SUB * KF_TILE];
+  const int seg = blockIdx.y;
+  const long long t0 = (long long)seg * seg_len;
+  const int len = (int)min((long long)seg_len, nt - t0);
+  knn2_fp4_scan(q, nq, (int)blockIdx.x, t + (size_t)t0 * 8, len, index_offset + (uint32_t)t0,
+                out_idx + (size_t)seg * nq * 2, out_dist + (size_t)seg * nq * 2, sA);
+}
+
+__global__ __launch_bounds__(256) void k_knn2_fp4_frames(const uint32_t* __restrict__ descL, int capL,
+                                                         const int* __restrict__ nL, const int* __restrict__ monoL,
+                                                         const uint32_t* __restrict__ descR, int capR,
+                                                         const int* __restrict__ nR, const int* __restrict__ monoR,
+                                                         uint32_t* __restrict__ out_idx,
+                                                         uint16_t* __restrict__ out_dist) {
+  __shared__ __align__(16) uint8_t sA[2][KF_SUB * KF_TILE];
+  const int f = blockIdx.y;
+  const int ml = monoL[f], mr = monoR[f];
+  const int nq = nL[f] - ml, nt = nR[f] - mr;
+  if ((int)blockIdx.x * KF_QPB >= nq) return;   // the whole workgroup
+  knn2_fp4_scan(descL + ((size_t)f * capL + ml) * 8, nq, (int)blockIdx.x, descR + ((size_t)f * capR + mr) * 8,
+                max(nt, 0), 0u, out_idx + (size_t)f * capL * 2, out_dist + (size_t)f * capL * 2, sA);
+}
+
 // Merge partial 2-NN lists by (distance, index); part p holds its nq*2 indices at idx_parts +
 // p*idx_stride bytes and its nq*2 distances at dist_parts + p*dist_stride bytes.  Parts are
 // visited in order and comparisons are strict, so equal (distance, index) pairs cannot reorder
@@ -426,7 +634,11 @@ namespace orbx {
 void launch_knn2_frames(const uint8_t* descL, int capL, const int* nL, const int* monoL, const uint8_t* descR,
                         int capR, const int* nR, const int* monoR, uint32_t* idx, uint16_t* dist, int nframes,
                         hipStream_t s) {
-  hipLaunchKernelGGL(k_knn2_mfma_frames, dim3((capL + KM_QPB - 1) / KM_QPB, nframes), dim3(256), 0, s,
+  const char* e = std::getenv("ORBX_KNN2_I8");
+  const bool i8 = e && e[0] == '1';
+  auto kern = i8 ? k_knn2_mfma_frames : k_knn2_fp4_frames;
+  const int qpb = i8 ? KM_QPB : KF_QPB;
+  hipLaunchKernelGGL(kern, dim3((capL + qpb - 1) / qpb, nframes), dim3(256), 0, s,
                      (const uint32_t*)descL, capL, nL, monoL, (const uint32_t*)descR, capR, nR, monoR, idx, dist);
 }
 void launch_ratio_test_frames(const uint32_t* idx, const uint16_t* dist, int cap, const int* nq, const int* mono,
@@ -470,19 +682,24 @@ struct KnnCut { int qblocks; long long segs; int seg_len; };
 static const size_t kPartialBytesPerQuery = 12;   // two uint32 indices + two uint16 distances
 
 // ORBX_KNN2_VALU=1 (timing knob, same results): the vector-ALU scan instead of the matrix-core one
-// (read at every call, so that a test can compare the two forms inside one process)
+// (read at every call, so that a test can compare the forms inside one process)
 static bool knn2_use_valu() {
   const char* e = std::getenv("ORBX_KNN2_VALU");
   return e && e[0] == '1';
 }
+// ORBX_KNN2_I8=1 (timing knob, same results): the int8 form of the matrix-core scan instead of the FP4 one
+static bool knn2_use_i8() {
+  const char* e = std::getenv("ORBX_KNN2_I8");
+  return e && e[0] == '1';
+}
 
 static int knn2_cut(int nq, int64_t nt, size_t partial_budget, KnnCut* c) {
-  const int qpb = knn2_use_valu() ? KNN_QPL * KNN_BLOCK : KM_QPB;   // queries per workgroup
+  const int qpb = knn2_use_valu() ? KNN_QPL * KNN_BLOCK : (knn2_use_i8() ? KM_QPB : KF_QPB);   // queries per workgroup
   c->qblocks = (nq + qpb - 1) / qpb;
   long long segs = 1, minSegs = 1;
   if (nt > 0) {
     // enough workgroups for some twenty rounds of the chip, so that the last round's idle CUs cost little
-    const long long want = ((knn2_use_valu() ? 2048 : 16384) + c->qblocks - 1) / c->qblocks;
+    const long long want = ((knn2_use_valu() ? 2048 : KNN_WANT_WGS) + c->qblocks - 1) / c->qblocks;
     const long long minLen = 512;
     segs = std::max(1LL, std::min(want, (long long)((nt + minLen - 1) / minLen)));
     const long long maxLen = 1LL << KNN_IDX_BITS;
@@ -507,7 +724,7 @@ static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 static int knn2_enqueue(const KnnCut& c, const uint8_t* d_q, int nq, const uint8_t* d_t, int64_t nt,
                         uint32_t index_offset, uint32_t* d_idx, uint16_t* d_dist, uint8_t* partial,
                         hipStream_t s) {
-  auto kern = knn2_use_valu() ? orbx::k_knn2 : orbx::k_knn2_mfma;
+  auto kern = knn2_use_valu() ? orbx::k_knn2 : (knn2_use_i8() ? orbx::k_knn2_mfma : orbx::k_knn2_fp4);
   if (c.segs == 1) {
     hipLaunchKernelGGL(kern, dim3(c.qblocks, 1), dim3(256), 0, s, (const uint32_t*)d_q, nq,
                        (const uint32_t*)d_t, (long long)nt, c.seg_len, index_offset, d_idx, d_dist);

@@ -241,6 +241,50 @@ inline sim_v16i mfma_i32_32x32x32_i8(int site, sim_v4i a, sim_v4i b, sim_v16i c)
 }
 #define __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, x, y, z) hostsim::mfma_i32_32x32x32_i8(__LINE__, (a), (b), (c))
 
+// v_mfma_scale_f32_32x32x64_f8f6f4 with both operands FP4 (e2m1; cbsz = blgp = 4) and both block
+// scales 2^0: D = A (32 x 64) * B (64 x 32) + C in f32.  Lane l holds row l & 31 of A and column
+// l & 31 of B for the 32 k values 32 (l >> 5) .. + 31, one per nibble of its first four dwords;
+// C / D as for the 32 x 32 integer form.  Other formats and scales are not emulated.
+typedef int sim_v8i __attribute__((ext_vector_type(8)));
+typedef float sim_v16f __attribute__((ext_vector_type(16)));
+inline float fp4_e2m1(unsigned c) {
+  const float mag[8] = {0.f, 0.5f, 1.f, 1.5f, 2.f, 3.f, 4.f, 6.f};
+  return (c & 8) ? -mag[c & 7] : mag[c & 7];
+}
+inline sim_v16f mfma_scale_f32_32x32x64_fp4(int site, sim_v8i a, sim_v8i b, sim_v16f c, int cbsz, int blgp, int opa,
+                                            int sa, int opb, int sb) {
+  if (cbsz != 4 || blgp != 4 || opa != 0 || opb != 0 || (sa & 0xFF) != 0x7f || (sb & 0xFF) != 0x7f)
+    fail("scaled mfma: only FP4 operands with unit scales are emulated", site);
+  uint64_t av[2][64], bv[2][64];
+  uint64_t mask = 0;
+  for (int half = 0; half < 2; ++half) {
+    const uint64_t am = ((uint64_t)(uint32_t)a[2 * half + 1] << 32) | (uint32_t)a[2 * half];
+    const uint64_t bm = ((uint64_t)(uint32_t)b[2 * half + 1] << 32) | (uint32_t)b[2 * half];
+    const Gathered ga = wave_gather(site, am);
+    for (int i = 0; i < 64; ++i) av[half][i] = ga.v[i];
+    const Gathered gb = wave_gather(site, bm);
+    for (int i = 0; i < 64; ++i) bv[half][i] = gb.v[i];
+    mask = gb.mask;
+  }
+  if (mask != ~0ull) fail("mfma with inactive lanes", site);
+  const int l = lane_in_wave(), n = l & 31;
+  sim_v16f d = c;
+  for (int i = 0; i < 16; ++i) {
+    const int m = (i & 3) + 8 * (i >> 2) + 4 * (l >> 5);
+    float sum = 0.f;
+    for (int hh = 0; hh < 2; ++hh)
+      for (int j = 0; j < 32; ++j) {
+        const float ab = fp4_e2m1((unsigned)(av[j >> 4][m + 32 * hh] >> (4 * (j & 15))) & 15u);
+        const float bb = fp4_e2m1((unsigned)(bv[j >> 4][n + 32 * hh] >> (4 * (j & 15))) & 15u);
+        sum += ab * bb;
+      }
+    d[i] += sum;
+  }
+  return d;
+}
+#define __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, cbsz, blgp, opa, sa, opb, sb) \
+  hostsim::mfma_scale_f32_32x32x64_fp4(__LINE__, (a), (b), (c), (cbsz), (blgp), (opa), (sa), (opb), (sb))
+
 // v_alignbyte_b32: bytes [sh, sh+4) of the 8-byte value hi:lo
 inline uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) {
   return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (8 * (sh & 3)));

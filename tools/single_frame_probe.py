@@ -20,3 +20,10 @@ t0 = time.perf_counter()
 for _ in range(200):
     ex(img, None, (0, 1000))
 print("host call (python wrapper included): %.3f ms" % ((time.perf_counter() - t0) / 200 * 1e3))
+ex.set_profiling(True)
+acc = {}
+for _ in range(50):
+    ex.extract_batch_device(d.data_ptr(), 1, W, H, W, (0, 1000)); ex.sync()
+    for k, v in ex.stage_times_ms().items():
+        acc[k] = acc.get(k, 0.0) + v / 50
+print("stages, one frame, serialised (ms):", {k: round(v, 4) for k, v in acc.items()})
