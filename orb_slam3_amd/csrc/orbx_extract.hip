@@ -38,20 +38,23 @@ __device__ __forceinline__ int mbcnt64(unsigned long long m) {
   return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
 
+// Inclusive prefix sum over the 64 lanes through the data-parallel-primitive forms of v_add: four
+// shifts inside every row of 16 lanes, then the last lane of row 0 / 2 into rows 1 / 3 and lane 31
+// into rows 2 and 3 - six instructions and no LDS round trip (a shuffle is an LDS permute plus a
+// select per step).  All 64 lanes must be active.
 __device__ __forceinline__ int wave_incl_scan(int v) {
-  const int lane = lane_id();
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    int t = __shfl_up(v, d, 64);
-    if (lane >= d) v += t;
-  }
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
   return v;
 }
 
+// the sum over the 64 lanes, in every lane
 __device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-  return v;
+  return __builtin_amdgcn_readlane(wave_incl_scan(v), 63);
 }
 
 // a.lo*b.lo + a.hi*b.hi + c on unsigned 16-bit halves (v_dot2_u32_u16)
@@ -1977,10 +1980,24 @@ __global__ __launch_bounds__(64) void k_orient_blur_describe(const Plan* __restr
     m10 = (int)sW - 16 * (int)sI;
     m01 = v * (int)sI;
   }
-#pragma unroll
-  for (int d = 16; d >= 1; d >>= 1) {
-    m10 += __shfl_xor(m10, d, 64);
-    m01 += __shfl_xor(m01, d, 64);
+  // sums over the keypoint's 32 lanes: prefix sums inside the rows of 16 lanes (no LDS round
+  // trips), then the two row totals of the keypoint's half of the wave
+  {
+    int s10 = m10, s01 = m01;
+    s10 += __builtin_amdgcn_update_dpp(0, s10, 0x111, 0xf, 0xf, true);
+    s01 += __builtin_amdgcn_update_dpp(0, s01, 0x111, 0xf, 0xf, true);
+    s10 += __builtin_amdgcn_update_dpp(0, s10, 0x112, 0xf, 0xf, true);
+    s01 += __builtin_amdgcn_update_dpp(0, s01, 0x112, 0xf, 0xf, true);
+    s10 += __builtin_amdgcn_update_dpp(0, s10, 0x114, 0xf, 0xf, true);
+    s01 += __builtin_amdgcn_update_dpp(0, s01, 0x114, 0xf, 0xf, true);
+    s10 += __builtin_amdgcn_update_dpp(0, s10, 0x118, 0xf, 0xf, true);
+    s01 += __builtin_amdgcn_update_dpp(0, s01, 0x118, 0xf, 0xf, true);
+    const int a10 = __builtin_amdgcn_readlane(s10, 15) + __builtin_amdgcn_readlane(s10, 31);
+    const int b10 = __builtin_amdgcn_readlane(s10, 47) + __builtin_amdgcn_readlane(s10, 63);
+    const int a01 = __builtin_amdgcn_readlane(s01, 15) + __builtin_amdgcn_readlane(s01, 31);
+    const int b01 = __builtin_amdgcn_readlane(s01, 47) + __builtin_amdgcn_readlane(s01, 63);
+    m10 = g ? b10 : a10;
+    m01 = g ? b01 : a01;
   }
   const float angle = fast_atan2_deg((float)m01, (float)m10);
 

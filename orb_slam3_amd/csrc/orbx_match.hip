@@ -350,7 +350,10 @@ __global__ __launch_bounds__(256) void k_knn2_mfma_frames(const uint32_t* __rest
 #ifndef KF_NQT
 #define KF_NQT 2                              // query tiles of 32 per wave
 #endif
-#define KF_QPB (KM_WAVES * KF_NQT * 32)       // queries per workgroup
+#ifndef KF_WAVES
+#define KF_WAVES 4                            // waves per workgroup
+#endif
+#define KF_QPB (KF_WAVES * KF_NQT * 32)       // queries per workgroup
 #ifndef KF_SUB
 #define KF_SUB 2                              // train tiles of 32 rows per stage
 #endif
@@ -417,20 +420,27 @@ __device__ __forceinline__ void knn2_fp4_scan(const uint32_t* __restrict__ q, in
   // ---- train tiles, KF_SUB of them per stage (one workgroup barrier per stage) ------
   // staging: this thread's row of a tile and word of the row; word sw = 2 s + h goes to the
   // operand slot of step s, half h
-  const int srow = tid & 31, sw = tid >> 5;
+  // (a stage is KF_SUB * 256 words; thread tid takes words tid, tid + threads, ...)
+  constexpr int kThreads = 64 * KF_WAVES;
+  constexpr int kPer = KF_SUB * 256 / kThreads;          // words per thread and stage
+  static_assert(KF_SUB * 256 % kThreads == 0, "stage words must divide over the workgroup");
   const int ntiles = (len + 31) >> 5;
   const int nstages = (ntiles + KF_SUB - 1) / KF_SUB;
-  uint32_t pre[KF_SUB];
+  uint32_t pre[kPer];
   auto fetch = [&](int stg) {
 #pragma unroll
-    for (int u = 0; u < KF_SUB; ++u) {
-      const int row = (stg * KF_SUB + u) * 32 + srow;
-      pre[u] = row < len ? tp[(size_t)row * 8 + sw] : 0u;
+    for (int u = 0; u < kPer; ++u) {
+      const int wi = tid + u * kThreads;                  // word of the stage: tile, word of the row, row
+      const int row = (stg * KF_SUB + (wi >> 8)) * 32 + (wi & 31);
+      pre[u] = row < len ? tp[(size_t)row * 8 + ((wi >> 5) & 7)] : 0u;
     }
   };
   auto stage = [&](int buf) {
 #pragma unroll
-    for (int u = 0; u < KF_SUB; ++u) *(km_v4i*)&sA[buf][u * KF_TILE + (sw * 32 + srow) * 16] = bits_to_fp4(pre[u]);
+    for (int u = 0; u < kPer; ++u) {
+      const int wi = tid + u * kThreads;
+      *(km_v4i*)&sA[buf][(wi >> 8) * KF_TILE + (((wi >> 5) & 7) * 32 + (wi & 31)) * 16] = bits_to_fp4(pre[u]);
+    }
   };
   if (nstages > 0) { fetch(0); stage(0); }
   __syncthreads();
@@ -509,7 +519,7 @@ __device__ __forceinline__ void knn2_fp4_scan(const uint32_t* __restrict__ q, in
   }
 }
 
-__global__ __launch_bounds__(256) void k_knn2_fp4(const uint32_t* __restrict__ q, int nq,
+__global__ __launch_bounds__(64 * KF_WAVES) void k_knn2_fp4(const uint32_t* __restrict__ q, int nq,
                                                   const uint32_t* __restrict__ t, long long nt,
                                                   int seg_len, uint32_t index_offset,
                                                   uint32_t* __restrict__ out_idx,
@@ -522,7 +532,7 @@ __global__ __launch_bounds__(256) void k_knn2_fp4(const uint32_t* __restrict__ q
                 out_idx + (size_t)seg * nq * 2, out_dist + (size_t)seg * nq * 2, sA);
 }
 
-__global__ __launch_bounds__(256) void k_knn2_fp4_frames(const uint32_t* __restrict__ descL, int capL,
+__global__ __launch_bounds__(64 * KF_WAVES) void k_knn2_fp4_frames(const uint32_t* __restrict__ descL, int capL,
                                                          const int* __restrict__ nL, const int* __restrict__ monoL,
                                                          const uint32_t* __restrict__ descR, int capR,
                                                          const int* __restrict__ nR, const int* __restrict__ monoR,
@@ -638,7 +648,7 @@ void launch_knn2_frames(const uint8_t* descL, int capL, const int* nL, const int
   const bool i8 = e && e[0] == '1';
   auto kern = i8 ? k_knn2_mfma_frames : k_knn2_fp4_frames;
   const int qpb = i8 ? KM_QPB : KF_QPB;
-  hipLaunchKernelGGL(kern, dim3((capL + qpb - 1) / qpb, nframes), dim3(256), 0, s,
+  hipLaunchKernelGGL(kern, dim3((capL + qpb - 1) / qpb, nframes), dim3(i8 ? 256 : 64 * KF_WAVES), 0, s,
                      (const uint32_t*)descL, capL, nL, monoL, (const uint32_t*)descR, capR, nR, monoR, idx, dist);
 }
 void launch_ratio_test_frames(const uint32_t* idx, const uint16_t* dist, int cap, const int* nq, const int* mono,
@@ -725,13 +735,14 @@ static int knn2_enqueue(const KnnCut& c, const uint8_t* d_q, int nq, const uint8
                         uint32_t index_offset, uint32_t* d_idx, uint16_t* d_dist, uint8_t* partial,
                         hipStream_t s) {
   auto kern = knn2_use_valu() ? orbx::k_knn2 : (knn2_use_i8() ? orbx::k_knn2_mfma : orbx::k_knn2_fp4);
+  const int threads = (knn2_use_valu() || knn2_use_i8()) ? 256 : 64 * KF_WAVES;
   if (c.segs == 1) {
-    hipLaunchKernelGGL(kern, dim3(c.qblocks, 1), dim3(256), 0, s, (const uint32_t*)d_q, nq,
+    hipLaunchKernelGGL(kern, dim3(c.qblocks, 1), dim3(threads), 0, s, (const uint32_t*)d_q, nq,
                        (const uint32_t*)d_t, (long long)nt, c.seg_len, index_offset, d_idx, d_dist);
   } else {
     uint8_t* pidx = partial;
     uint8_t* pdist = partial + align256((size_t)c.segs * nq * 8);
-    hipLaunchKernelGGL(kern, dim3(c.qblocks, (unsigned)c.segs), dim3(256), 0, s,
+    hipLaunchKernelGGL(kern, dim3(c.qblocks, (unsigned)c.segs), dim3(threads), 0, s,
                        (const uint32_t*)d_q, nq, (const uint32_t*)d_t, (long long)nt, c.seg_len,
                        index_offset, (uint32_t*)pidx, (uint16_t*)pdist);
     hipLaunchKernelGGL(orbx::k_top2_merge, dim3((nq + 255) / 256), dim3(256), 0, s, pidx, (size_t)nq * 8,

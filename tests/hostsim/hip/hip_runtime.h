@@ -206,6 +206,30 @@ template <class T> inline T readfirstlane(int site, T v) {
 }
 inline void wave_barrier(int site) { (void)wave_gather(site, 0); }
 
+// v_mov_b32 with a DPP control, as __builtin_amdgcn_update_dpp gives it: the lane takes src of the
+// lane the control names; a lane whose row or bank is masked out, or whose source lane does not
+// exist or is inactive while bound_ctrl is clear, keeps `old`; with bound_ctrl set a missing
+// source reads as 0.  Emulated controls: row_shr:1..15 (0x111..0x11f), row_bcast:15 (0x142),
+// row_bcast:31 (0x143).
+inline uint32_t update_dpp(int site, uint32_t old, uint32_t src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+  const Gathered g = wave_gather(site, src);
+  const int lane = lane_in_wave(), row = lane >> 4, inrow = lane & 15;
+  if (!((row_mask >> row) & 1) || !((bank_mask >> (inrow >> 2)) & 1)) return old;
+  int from = -1;
+  if (ctrl >= 0x111 && ctrl <= 0x11f) {
+    const int n = ctrl - 0x110;
+    from = inrow >= n ? lane - n : -1;
+  } else if (ctrl == 0x142) {
+    from = row >= 1 ? 16 * row - 1 : -1;
+  } else if (ctrl == 0x143) {
+    from = row >= 2 ? 31 : -1;
+  } else {
+    fail("update_dpp: control not emulated", site);
+  }
+  if (from < 0 || !((g.mask >> from) & 1)) return bound_ctrl ? 0u : old;
+  return (uint32_t)g.v[from];
+}
+
 // v_mfma_i32_32x32x32_i8: D = A (32 x 32, signed bytes) * B (32 x 32) + C.  Lane l holds row l & 31
 // of A and column l & 31 of B for the 16 k values 16 (l >> 5) .. + 15 (one per byte of its four
 // dwords), and of C / D column l & 31, rows (i & 3) + 8 (i >> 2) + 4 (l >> 5) for register i.
@@ -355,6 +379,9 @@ inline void launch_kernel(const char* name, dim3 grid, dim3 block, size_t lds, K
 #define __syncthreads() hostsim::block_barrier(__LINE__)
 #define __syncthreads_or(p) hostsim::block_barrier_or(__LINE__, (p))
 #define __builtin_amdgcn_readfirstlane(v) hostsim::readfirstlane(__LINE__, (v))
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) \
+  ((int)hostsim::update_dpp(__LINE__, (uint32_t)(old), (uint32_t)(src), (ctrl), (rm), (bm), (bc)))
+#define __builtin_amdgcn_readlane(v, l) hostsim::shfl(__LINE__, (v), (l))
 #define __builtin_amdgcn_wave_barrier() hostsim::wave_barrier(__LINE__)
 #define __builtin_amdgcn_fence(...) ((void)0)
 #define __builtin_amdgcn_s_barrier() hostsim::block_barrier(__LINE__)
