@@ -436,6 +436,54 @@ int orbx_search_by_projection_last(orbx_extractor* cur, int frame, int n_last, c
                                    const uint8_t* last_obs, const float* u_right, const uint8_t* state,
                                    float th, int forward, int backward, float mbf, int check_orientation,
                                    int32_t* assigned, int cap, int* n_out, int* nmatches, int* rounds);
+/* The same matcher for a current frame with two cameras (CurrentFrame.Nleft != -1,
+ * a fisheye rig), core/lib/ORB/matcher.cc:1591-1808 with the right camera's pass
+ * of :1712-1786: `left` and `right` hold the two cameras' extractions and grids
+ * for `frame` (orbx_frame_grid_batch_device on each, same image bounds), the
+ * reference's keypoint index i2 >= Nleft being right keypoint i2 - Nleft here.
+ * uv_left / uv_right: the map point's projections into the two cameras (the
+ * second through GetRelativePoseTrl, :1713-1714).  As in the reference the left
+ * camera's checks gate the right camera's search: a point behind the camera,
+ * with a left projection outside the image, or with an empty left window is not
+ * searched in the right camera either; the right projection itself is not
+ * checked against the image; the mvuRight test does not apply.  One rotation
+ * histogram covers both cameras.  assigned_left / assigned_right, state_left /
+ * state_right as assigned / state above, per camera.  *nmatches = the return
+ * value.  Blocks. */
+int orbx_search_by_projection_last_rig(orbx_extractor* left, orbx_extractor* right, int frame, int n_last,
+                                       const uint8_t* last_valid, const float* uv_left, const float* invz,
+                                       const float* uv_right, const int32_t* last_octave, const float* last_angle,
+                                       const uint8_t* last_desc, const uint8_t* last_obs, const uint8_t* state_left,
+                                       const uint8_t* state_right, float th, int forward, int backward,
+                                       int check_orientation, int32_t* assigned_left, int cap_left, int* n_left,
+                                       int32_t* assigned_right, int cap_right, int* n_right, int* nmatches,
+                                       int* rounds);
+/* ORBmatcher::SearchByProjection(F, vpMapPoints, th, bFarPoints, thFarPoints) for
+ * a frame with two cameras (F.Nleft != -1), core/lib/ORB/matcher.cc:41-213: per
+ * map point the left camera's search (:60-142), whose match is also written
+ * into the keypoint's stereo partner in the right camera (mvLeftToRightMatch,
+ * :129-135), then the right camera's search (:144-210) around proj_right at
+ * level_right, whose match is also written into the partner in the left camera
+ * (mvRightToLeftMatch, :197-203).  in_view_right / proj_right / level_right /
+ * view_cos_right: mbTrackInViewR, mTrackProjXR / mTrackProjYR,
+ * mnTrackScaleLevelR (-1 = none: no right search, :146), mTrackViewCosR.
+ * left_to_right[n_left] / right_to_left[n_right]: partner index in the other
+ * camera's own numbering, -1 none.  Kept from the reference: a left search whose
+ * best candidate fails the ratio test skips the right camera too (:123-124); the
+ * right camera's radius ignores th (:147); a partner receives the map point
+ * whatever it held, so a keypoint closed by a point with observations opens again
+ * when it receives one without; every write counts in *nmatches.  assigned_* /
+ * state_* per camera as in orbx_search_by_projection_points.  n_points at most
+ * half the single-camera limit.  Blocks. */
+int orbx_search_by_projection_points_rig(orbx_extractor* left, orbx_extractor* right, int frame, int n_points,
+                                         const uint8_t* in_view, const float* proj, const int32_t* level,
+                                         const float* view_cos, const uint8_t* in_view_right, const float* proj_right,
+                                         const int32_t* level_right, const float* view_cos_right, const uint8_t* desc,
+                                         const uint8_t* obs, const int32_t* left_to_right,
+                                         const int32_t* right_to_left, const uint8_t* state_left,
+                                         const uint8_t* state_right, float th, float nnratio, int32_t* assigned_left,
+                                         int cap_left, int* n_left, int32_t* assigned_right, int cap_right,
+                                         int* n_right, int* nmatches, int* rounds);
 /* ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist),
  * core/lib/ORB/matcher.cc:1810-1923 (relocalisation).  One entry per keypoint
  * of the keyframe; the caller's part is :1826-1853:

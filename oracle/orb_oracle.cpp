@@ -1239,6 +1239,209 @@ int orc_search_by_projection_points(const uint8_t* inView, const float* proj, co
   return nmatches;
 }
 
+// ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono), core/lib/ORB/matcher.cc:1591-1808,
+// for a current frame with two cameras (CurrentFrame.Nleft != -1: a fisheye rig): after the left
+// camera's search (:1632-1711) every last-frame keypoint that got that far is searched again
+// among the RIGHT camera's keypoints around its projection into the right camera (:1712-1786).
+// The two keypoint sets are given separately (left: kpsL, descL, gridL; right: kpsR, descR, gridR;
+// the reference keeps them in one array with the right ones at index + Nleft); uvR is the
+// projection through Trl (:1713-1714), computed by the caller like uvL.  Quirks kept: the left
+// camera's checks gate the right camera's search (behind the camera :1624, left projection
+// outside the image :1629-1632, and an EMPTY left window, whose `continue` at :1652 leaves the
+// loop body); the right projection is not checked against the image; with two cameras the
+// mvuRight test of :1669-1674 does not apply.  One rotation histogram for both cameras.
+int orc_search_by_projection_last_rig(const uint8_t* lastValid, const float* uvL, const float* invz,
+                                      const float* uvR, const int* lastOctave, const float* lastAngle,
+                                      const uint8_t* lastDesc, const uint8_t* lastObs, int nLast,
+                                      const void* kpsL28, const uint8_t* descL, const uint8_t* stateL, int nL,
+                                      const int* cellStartL, const int* entriesL, const void* kpsR28,
+                                      const uint8_t* descR, const uint8_t* stateR, int nR, const int* cellStartR,
+                                      const int* entriesR, const float* bounds, const float* scaleFactors,
+                                      float th, int forward, int backward, int checkOrientation, int* assignedL,
+                                      int* assignedR) {
+  const KeyPoint* KL = (const KeyPoint*)kpsL28;
+  const KeyPoint* KR = (const KeyPoint*)kpsR28;
+  const int TH_HIGH = 100;
+  int nmatches = 0;
+  for (int i = 0; i < nL; ++i) assignedL[i] = -1;
+  for (int i = 0; i < nR; ++i) assignedR[i] = -1;
+  std::vector<uint8_t> blockedL(std::max(nL, 1)), blockedR(std::max(nR, 1));
+  for (int i = 0; i < nL; ++i) blockedL[i] = stateL[i] == 1;
+  for (int i = 0; i < nR; ++i) blockedR[i] = stateR[i] == 1;
+  // histogram entries: keypoint index, +nL for the right camera (the reference's index + Nleft)
+  std::vector<std::vector<int>> rotHist(kHistoLength);
+  std::vector<int> idx(std::max(std::max(nL, nR), 1));
+  for (int i = 0; i < nLast; ++i) {
+    if (!lastValid[i]) continue;
+    if (invz[i] < 0) continue;
+    const float u = uvL[2 * i], v = uvL[2 * i + 1];
+    if (u < bounds[0] || u > bounds[1]) continue;
+    if (v < bounds[2] || v > bounds[3]) continue;
+    const int nLastOctave = lastOctave[i];
+    const float radius = th * scaleFactors[nLastOctave];
+    int minL, maxL;
+    if (forward) { minL = nLastOctave; maxL = -1; }
+    else if (backward) { minL = 0; maxL = nLastOctave; }
+    else { minL = nLastOctave - 1; maxL = nLastOctave + 1; }
+    int found = orc_features_in_area(bounds, kpsL28, cellStartL, entriesL, u, v, radius, minL, maxL, idx.data(), nL);
+    if (found == 0) continue;   // :1652, also skips the right camera
+    int bestDist = 256, bestIdx2 = -1;
+    for (int c = 0; c < found; ++c) {
+      const int i2 = idx[c];
+      if (blockedL[i2]) continue;
+      const int dist = hamming256(lastDesc + (size_t)i * 32, descL + (size_t)i2 * 32);
+      if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+    }
+    if (bestDist <= TH_HIGH) {
+      assignedL[bestIdx2] = i;
+      blockedL[bestIdx2] = lastObs[i] != 0;
+      nmatches++;
+      if (checkOrientation) rotHist[rotationBin(lastAngle[i], KL[bestIdx2].angle)].push_back(bestIdx2);
+    }
+    // ---- the right camera, :1712-1786
+    found = orc_features_in_area(bounds, kpsR28, cellStartR, entriesR, uvR[2 * i], uvR[2 * i + 1], radius, minL, maxL,
+                                 idx.data(), nR);
+    bestDist = 256; bestIdx2 = -1;
+    for (int c = 0; c < found; ++c) {
+      const int i2 = idx[c];
+      if (blockedR[i2]) continue;
+      const int dist = hamming256(lastDesc + (size_t)i * 32, descR + (size_t)i2 * 32);
+      if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+    }
+    if (bestDist <= TH_HIGH) {
+      assignedR[bestIdx2] = i;
+      blockedR[bestIdx2] = lastObs[i] != 0;
+      nmatches++;
+      if (checkOrientation) rotHist[rotationBin(lastAngle[i], KR[bestIdx2].angle)].push_back(bestIdx2 + nL);
+    }
+  }
+  if (checkOrientation) {
+    int sizes[kHistoLength], ind[3];
+    for (int i = 0; i < kHistoLength; ++i) sizes[i] = (int)rotHist[i].size();
+    orc_three_maxima(sizes, kHistoLength, ind);
+    for (int i = 0; i < kHistoLength; ++i) {
+      if (i == ind[0] || i == ind[1] || i == ind[2]) continue;
+      for (int e : rotHist[i]) {
+        if (e < nL) assignedL[e] = -2; else assignedR[e - nL] = -2;
+        nmatches--;
+      }
+    }
+  }
+  return nmatches;
+}
+
+// ORBmatcher::SearchByProjection(F, vpMapPoints, th, bFarPoints, thFarPoints), matcher.cc:41-213,
+// for a frame with two cameras (F.Nleft != -1).  Per map point first the left camera's search
+// (:64-142; without the mvuRight test, which needs F.Nleft == -1), whose match is also given to
+// the keypoint's stereo partner in the right camera (mvLeftToRightMatch, :129-135); then, if the
+// point is in the right camera's view and has a predicted level there, the right camera's search
+// (:144-210), whose match is also given to the partner in the left camera (mvRightToLeftMatch,
+// :197-203).  Quirks kept: a left search that finds a best candidate within TH_HIGH but fails
+// the ratio test leaves the loop body (`continue`, :124-125) and so skips the right camera; the
+// right camera's radius is not multiplied by th (:147); a partner receives the map point whatever
+// it held before, so a keypoint that held a point with observations can come to hold one without.
+// inView / inViewR already contain the far-point and isBad tests (:51-60).  leftToRight[i] /
+// rightToLeft[j]: partner index in the other camera's own numbering, or -1.
+int orc_search_by_projection_points_rig(const uint8_t* inView, const float* proj, const int* level,
+                                        const float* viewCos, const uint8_t* inViewR, const float* projR,
+                                        const int* levelR, const float* viewCosR, const uint8_t* ptDesc,
+                                        const uint8_t* ptObs, int nPts, const void* kpsL28, const uint8_t* descL,
+                                        const uint8_t* stateL, int nL, const int* cellStartL, const int* entriesL,
+                                        const void* kpsR28, const uint8_t* descR, const uint8_t* stateR, int nR,
+                                        const int* cellStartR, const int* entriesR, const int* leftToRight,
+                                        const int* rightToLeft, const float* bounds, const float* scaleFactors,
+                                        float th, float nnratio, int* assignedL, int* assignedR) {
+  const KeyPoint* KL = (const KeyPoint*)kpsL28;
+  const KeyPoint* KR = (const KeyPoint*)kpsR28;
+  const int TH_HIGH = 100;
+  int nmatches = 0;
+  for (int i = 0; i < nL; ++i) assignedL[i] = -1;
+  for (int i = 0; i < nR; ++i) assignedR[i] = -1;
+  std::vector<uint8_t> blockedL(std::max(nL, 1)), blockedR(std::max(nR, 1));
+  for (int i = 0; i < nL; ++i) blockedL[i] = stateL[i] == 1;
+  for (int i = 0; i < nR; ++i) blockedR[i] = stateR[i] == 1;
+  std::vector<int> idx(std::max(std::max(nL, nR), 1));
+  const bool bFactor = th != 1.0;
+  for (int iMP = 0; iMP < nPts; ++iMP) {
+    if (!inView[iMP] && !inViewR[iMP]) continue;
+    const uint8_t obs = ptObs[iMP] != 0;
+    if (inView[iMP]) {
+      const int nPredictedLevel = level[iMP];
+      float r = viewCos[iMP] > 0.998 ? 2.5f : 4.0f;
+      if (bFactor) r *= th;
+      const float radius = r * scaleFactors[nPredictedLevel];
+      const int found = orc_features_in_area(bounds, kpsL28, cellStartL, entriesL, proj[2 * iMP], proj[2 * iMP + 1],
+                                             radius, nPredictedLevel - 1, nPredictedLevel, idx.data(), nL);
+      if (found > 0) {
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int c = 0; c < found; ++c) {
+          const int i2 = idx[c];
+          if (blockedL[i2]) continue;
+          const int dist = hamming256(ptDesc + (size_t)iMP * 32, descL + (size_t)i2 * 32);
+          if (dist < bestDist) {
+            bestDist2 = bestDist; bestDist = dist;
+            bestLevel2 = bestLevel; bestLevel = KL[i2].octave;
+            bestIdx = i2;
+          } else if (dist < bestDist2) {
+            bestLevel2 = KL[i2].octave;
+            bestDist2 = dist;
+          }
+        }
+        if (bestDist <= TH_HIGH) {
+          if (bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) continue;   // :124-125
+          if (bestLevel != bestLevel2 || (float)bestDist <= nnratio * (float)bestDist2) {
+            assignedL[bestIdx] = iMP;
+            blockedL[bestIdx] = obs;
+            if (leftToRight[bestIdx] != -1) {
+              assignedR[leftToRight[bestIdx]] = iMP;
+              blockedR[leftToRight[bestIdx]] = obs;
+              nmatches++;
+            }
+            nmatches++;
+          }
+        }
+      }
+    }
+    if (inViewR[iMP]) {
+      const int nPredictedLevel = levelR[iMP];
+      if (nPredictedLevel != -1) {
+        const float r = viewCosR[iMP] > 0.998 ? 2.5f : 4.0f;
+        const float radius = r * scaleFactors[nPredictedLevel];
+        const int found = orc_features_in_area(bounds, kpsR28, cellStartR, entriesR, projR[2 * iMP],
+                                               projR[2 * iMP + 1], radius, nPredictedLevel - 1, nPredictedLevel,
+                                               idx.data(), nR);
+        if (found == 0) continue;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int c = 0; c < found; ++c) {
+          const int i2 = idx[c];
+          if (blockedR[i2]) continue;
+          const int dist = hamming256(ptDesc + (size_t)iMP * 32, descR + (size_t)i2 * 32);
+          if (dist < bestDist) {
+            bestDist2 = bestDist; bestDist = dist;
+            bestLevel2 = bestLevel; bestLevel = KR[i2].octave;
+            bestIdx = i2;
+          } else if (dist < bestDist2) {
+            bestLevel2 = KR[i2].octave;
+            bestDist2 = dist;
+          }
+        }
+        if (bestDist <= TH_HIGH) {
+          if (bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) continue;
+          if (rightToLeft[bestIdx] != -1) {
+            assignedL[rightToLeft[bestIdx]] = iMP;
+            blockedL[rightToLeft[bestIdx]] = obs;
+            nmatches++;
+          }
+          assignedR[bestIdx] = iMP;
+          blockedR[bestIdx] = obs;
+          nmatches++;
+        }
+      }
+    }
+  }
+  return nmatches;
+}
+
 // Frame::ComputeStereoFromRGBD, core/src/Frame.cc:998-1016.  depthImg: H rows of stride floats.
 void orc_stereo_from_rgbd(const void* kps28, const void* kpsUn28, int n, const float* depthImg, int stride,
                           float mbf, float* uRight, float* depth) {

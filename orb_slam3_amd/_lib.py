@@ -110,6 +110,12 @@ SIGNATURES = {
     "orbx_search_by_projection_last": (C.c_int, [_P, C.c_int, C.c_int, _P, _f32p, _f32p, _i32p, _f32p, _P, _P, _P, _P,
                                                  C.c_float, C.c_int, C.c_int, C.c_float, C.c_int, _P, C.c_int,
                                                  _i32p, _i32p, _i32p]),
+    "orbx_search_by_projection_last_rig": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _f32p, _f32p, _f32p, _i32p, _f32p, _P, _P,
+                                                     _P, _P, C.c_float, C.c_int, C.c_int, C.c_int, _P, C.c_int, _i32p,
+                                                     _P, C.c_int, _i32p, _i32p, _i32p]),
+    "orbx_search_by_projection_points_rig": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _f32p, _i32p, _f32p, _P, _f32p, _i32p,
+                                                       _f32p, _P, _P, _i32p, _i32p, _P, _P, C.c_float, C.c_float, _P,
+                                                       C.c_int, _i32p, _P, C.c_int, _i32p, _i32p, _i32p]),
     "orbx_search_by_projection_points": (C.c_int, [_P, C.c_int, C.c_int, _P, _f32p, _f32p, _i32p, _f32p, _P, _P, _P, _P,
                                                    C.c_float, C.c_float, _P, C.c_int, _i32p, _i32p, _i32p]),
     "orbx_lapping_knn2": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, _i32p, _i32p, _i32p, _i32p]),

@@ -83,6 +83,28 @@ void launch_search_by_bow(const uint8_t* d_kfValid, const float* d_kfAngle, cons
                           const float* d_kps, const uint8_t* d_desc, const int* d_n, int cap, const uint32_t* d_fNode,
                           const int* d_fStart, const uint32_t* d_fFeat, const int* d_fCount, float nnratio,
                           int checkOrientation, int* d_matches, int* d_summary, hipStream_t s);
+void launch_search_by_projection_last_rig(const uint8_t* d_lastValid, const float* d_uvL, const float* d_invz,
+                                          const float* d_uvR, const int* d_lastOctave, const float* d_lastAngle,
+                                          const uint8_t* d_lastDesc, const uint8_t* d_lastObs, int nLast,
+                                          const float* d_kpsL, const uint8_t* d_descL, const uint8_t* d_stateL, int nL,
+                                          const int* d_cellStartL, const int* d_entriesL, const float* d_kpsR,
+                                          const uint8_t* d_descR, const uint8_t* d_stateR, int nR,
+                                          const int* d_cellStartR, const int* d_entriesR, const float* bounds,
+                                          const float* scaleFactors, int nlevels, float th, int forward, int backward,
+                                          int checkOrientation, int* d_workL, int* d_workR, int* d_assignedL,
+                                          int* d_assignedR, int* d_sumL, int* d_sumR, int* d_summary, hipStream_t s);
+size_t points_rig_work_ints(int nPts, int nL, int nR);
+void launch_search_by_projection_points_rig(const uint8_t* d_inView, const float* d_proj, const int* d_level,
+                                            const float* d_viewCos, const uint8_t* d_inViewR, const float* d_projR,
+                                            const int* d_levelR, const float* d_viewCosR, const uint8_t* d_ptDesc,
+                                            const uint8_t* d_ptObs, int nPts, const float* d_kpsL,
+                                            const uint8_t* d_descL, const uint8_t* d_stateL, int nL,
+                                            const int* d_cellStartL, const int* d_entriesL, const float* d_kpsR,
+                                            const uint8_t* d_descR, const uint8_t* d_stateR, int nR,
+                                            const int* d_cellStartR, const int* d_entriesR, const int* d_leftToRight,
+                                            const int* d_rightToLeft, const float* bounds, const float* scaleFactors,
+                                            int nlevels, float th, float nnratio, int* d_work, int* d_assignedL,
+                                            int* d_assignedR, int* d_summary, hipStream_t s);
 void launch_search_by_projection_points(const uint8_t* d_inView, const float* d_proj, const float* d_projXR,
                                         const int* d_level, const float* d_viewCos, const uint8_t* d_ptDesc,
                                         const uint8_t* d_ptObs, int nPts, const float* d_kpsUn, const uint8_t* d_desc,
@@ -1847,6 +1869,102 @@ int orbx_search_by_projection_keyframe(orbx_extractor* cur, int frame, int n_kf,
   }
 }
 
+// the two handles of a rig frame: same device, both with a grid of the same bounds for `frame`
+static int rig_check(const orbx_extractor* l, const orbx_extractor* r, int frame) {
+  if (!l || !r || l == r || !l->planned || !r->planned || !l->d_kpsUn || !r->d_kpsUn || l->device != r->device)
+    return ORBX_ERR_BAD_ARG;
+  if (frame < 0 || frame >= l->gridFrames || frame >= r->gridFrames) return ORBX_ERR_BAD_ARG;
+  if (l->prm.nlevels != r->prm.nlevels || l->prm.scale_factor != r->prm.scale_factor) return ORBX_ERR_BAD_ARG;
+  for (int k = 0; k < 4; ++k)
+    if (l->gridBounds[k] != r->gridBounds[k]) return ORBX_ERR_BAD_ARG;   // one Frame, one set of image bounds
+  return ORBX_OK;
+}
+
+int orbx_search_by_projection_last_rig(orbx_extractor* left, orbx_extractor* right, int frame, int n_last,
+                                       const uint8_t* last_valid, const float* uv_left, const float* invz,
+                                       const float* uv_right, const int32_t* last_octave, const float* last_angle,
+                                       const uint8_t* last_desc, const uint8_t* last_obs, const uint8_t* state_left,
+                                       const uint8_t* state_right, float th, int forward, int backward,
+                                       int check_orientation, int32_t* assigned_left, int cap_left, int* n_left,
+                                       int32_t* assigned_right, int cap_right, int* n_right, int* nmatches,
+                                       int* rounds) {
+  if (const int rc_ = rig_check(left, right, frame)) return rc_;
+  if (n_last < 0 || n_last > kGuidedMaxQueries || cap_left < 0 || cap_right < 0 || !nmatches) return ORBX_ERR_BAD_ARG;
+  if (n_last > 0 && (!last_valid || !uv_left || !uv_right || !invz || !last_octave || !last_angle || !last_desc || !last_obs))
+    return ORBX_ERR_BAD_ARG;
+  orbx_extractor* ex = left;
+  for (int i = 0; i < n_last; ++i)
+    if (last_valid[i] && (last_octave[i] < 0 || last_octave[i] >= ex->prm.nlevels)) return ORBX_ERR_BAD_ARG;
+  if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  if (const int js_ = ex->joinParts()) return js_;
+  if (const int js_ = right->joinParts()) return js_;
+  auto& last_hip_error = ex->last_hip_error;
+  hipStream_t s = ex->stream;
+  if (!ex->evStereo) HIP_TRY(hipEventCreateWithFlags(&ex->evStereo, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(ex->evStereo, right->stream));   // the right camera's extraction and grid ran on its own stream
+  HIP_TRY(hipStreamWaitEvent(s, ex->evStereo, 0));
+  int nn[2] = {0, 0};
+  HIP_TRY(hipMemcpyAsync(&nn[0], ex->d_n + frame, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(&nn[1], right->d_n + frame, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  const int nL = nn[0], nR = nn[1];
+  if (n_left) *n_left = nL;
+  if (n_right) *n_right = nR;
+  *nmatches = 0;
+  if (rounds) *rounds = 0;
+  if (nL > cap_left || nR > cap_right) return ORBX_ERR_CAPACITY;
+  if ((nL > 0 && !assigned_left) || (nR > 0 && !assigned_right)) return ORBX_ERR_BAD_ARG;
+  for (int i = 0; i < nL; ++i) assigned_left[i] = -1;
+  for (int i = 0; i < nR; ++i) assigned_right[i] = -1;
+  if (n_last == 0 || nL == 0) return ORBX_OK;   // nothing passes the left camera's search: the right one is never reached
+  const size_t nl = (size_t)n_last, nnl = (size_t)nL, nnr = (size_t)std::max(nR, 1);
+  Carver c;
+  const size_t oValid = c.add(nl), oUvL = c.add(nl * 8), oUvR = c.add(nl * 8), oInvz = c.add(nl * 4),
+               oOct = c.add(nl * 4), oAng = c.add(nl * 4), oDesc = c.add(nl * 32), oObs = c.add(nl),
+               oStL = c.add(nnl), oStR = c.add(nnr),
+               oWorkL = c.add((orbx::projection_work_ints(n_last, nL) + nl) * 4),
+               oWorkR = c.add((orbx::projection_work_ints(n_last, (int)nnr) + nl) * 4), oAsgL = c.add(nnl * 4),
+               oAsgR = c.add(nnr * 4), oSum = c.add(24);
+  uint8_t* d = nullptr;
+  hipError_t e = hipMallocAsync((void**)&d, c.total, s);
+  if (e != hipSuccess) { last_hip_error = e; return ORBX_ERR_HIP; }
+  PackedUpload pk;
+  if (!pk.init(oWorkL)) { (void)hipFreeAsync(d, s); return ORBX_ERR_UNSUPPORTED; }
+  auto up = [&](size_t off, const void* src, size_t bytes) { pk.add(off, src, bytes); };
+  up(oValid, last_valid, nl); up(oUvL, uv_left, nl * 8); up(oUvR, uv_right, nl * 8); up(oInvz, invz, nl * 4);
+  up(oOct, last_octave, nl * 4); up(oAng, last_angle, nl * 4); up(oDesc, last_desc, nl * 32); up(oObs, last_obs, nl);
+  if (state_left) up(oStL, state_left, nnl);
+  if (state_right && nR > 0) up(oStR, state_right, (size_t)nR);
+  e = pk.send(d, s);
+  int sum[2] = {0, 0};
+  if (e == hipSuccess) {
+    const size_t bL = (size_t)frame * ex->hp.kp_cap, bR = (size_t)frame * right->hp.kp_cap;
+    orbx::launch_search_by_projection_last_rig(
+        d + oValid, (const float*)(d + oUvL), (const float*)(d + oInvz), (const float*)(d + oUvR),
+        (const int*)(d + oOct), (const float*)(d + oAng), d + oDesc, d + oObs, n_last, ex->d_kpsUn + bL * 7,
+        ex->d_desc + bL * 32, state_left ? d + oStL : nullptr, nL,
+        ex->d_cellStart + (size_t)frame * (ORBX_GRID_CELLS + 1), ex->d_cellEntries + bL, right->d_kpsUn + bR * 7,
+        right->d_desc + bR * 32, (state_right && nR > 0) ? d + oStR : nullptr, nR,
+        right->d_cellStart + (size_t)frame * (ORBX_GRID_CELLS + 1), right->d_cellEntries + bR, ex->gridBounds,
+        ex->scale.data(), ex->prm.nlevels, th, forward != 0, backward != 0, check_orientation != 0,
+        (int*)(d + oWorkL), (int*)(d + oWorkR), (int*)(d + oAsgL), (int*)(d + oAsgR), (int*)(d + oSum),
+        (int*)(d + oSum + 8), (int*)(d + oSum + 16), s);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(assigned_left, d + oAsgL, nnl * 4, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess && nR > 0) e = hipMemcpyAsync(assigned_right, d + oAsgR, (size_t)nR * 4, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(sum, d + oSum + 16, 8, hipMemcpyDeviceToHost, s);
+  {   // also after an error: the packed host block must outlive whatever was enqueued
+    const hipError_t es = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = es;
+  }
+  (void)hipFreeAsync(d, s);
+  if (e != hipSuccess) { last_hip_error = e; return ORBX_ERR_HIP; }
+  *nmatches = sum[0];
+  if (rounds) *rounds = sum[1];
+  return ORBX_OK;
+}
+
 int orbx_search_by_projection_points(orbx_extractor* f, int frame, int n_points, const uint8_t* in_view,
                                      const float* proj, const float* proj_xr, const int32_t* level,
                                      const float* view_cos, const uint8_t* desc, const uint8_t* obs,
@@ -1905,6 +2023,106 @@ int orbx_search_by_projection_points(orbx_extractor* f, int frame, int n_points,
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipMemcpyAsync(assigned, d + oAsg, nn * 4, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(sum, d + oSum, 8, hipMemcpyDeviceToHost, s);
+  {   // also after an error: the packed host block must outlive whatever was enqueued
+    const hipError_t es = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = es;
+  }
+  (void)hipFreeAsync(d, s);
+  if (e != hipSuccess) { last_hip_error = e; return ORBX_ERR_HIP; }
+  *nmatches = sum[0];
+  if (rounds) *rounds = sum[1];
+  return ORBX_OK;
+}
+
+int orbx_search_by_projection_points_rig(orbx_extractor* left, orbx_extractor* right, int frame, int n_points,
+                                         const uint8_t* in_view, const float* proj, const int32_t* level,
+                                         const float* view_cos, const uint8_t* in_view_right, const float* proj_right,
+                                         const int32_t* level_right, const float* view_cos_right, const uint8_t* desc,
+                                         const uint8_t* obs, const int32_t* left_to_right,
+                                         const int32_t* right_to_left, const uint8_t* state_left,
+                                         const uint8_t* state_right, float th, float nnratio, int32_t* assigned_left,
+                                         int cap_left, int* n_left, int32_t* assigned_right, int cap_right,
+                                         int* n_right, int* nmatches, int* rounds) {
+  if (const int rc_ = rig_check(left, right, frame)) return rc_;
+  if (n_points < 0 || n_points > kGuidedMaxQueries / 2 || cap_left < 0 || cap_right < 0 || !nmatches)
+    return ORBX_ERR_BAD_ARG;
+  if (n_points > 0 && (!in_view || !proj || !level || !view_cos || !in_view_right || !proj_right || !level_right ||
+                       !view_cos_right || !desc || !obs))
+    return ORBX_ERR_BAD_ARG;
+  orbx_extractor* ex = left;
+  // the right camera's search needs a predicted level there (:146); fold that into its in-view flag
+  std::vector<uint8_t> viewR((size_t)std::max(n_points, 1));
+  for (int i = 0; i < n_points; ++i) {
+    if (in_view[i] && (level[i] < 0 || level[i] >= ex->prm.nlevels)) return ORBX_ERR_BAD_ARG;
+    viewR[i] = in_view_right[i] && level_right[i] != -1;
+    if (viewR[i] && (level_right[i] < 0 || level_right[i] >= ex->prm.nlevels)) return ORBX_ERR_BAD_ARG;
+  }
+  if (hipSetDevice(ex->device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+  if (const int js_ = ex->joinParts()) return js_;
+  if (const int js_ = right->joinParts()) return js_;
+  auto& last_hip_error = ex->last_hip_error;
+  hipStream_t s = ex->stream;
+  if (!ex->evStereo) HIP_TRY(hipEventCreateWithFlags(&ex->evStereo, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(ex->evStereo, right->stream));
+  HIP_TRY(hipStreamWaitEvent(s, ex->evStereo, 0));
+  int nn[2] = {0, 0};
+  HIP_TRY(hipMemcpyAsync(&nn[0], ex->d_n + frame, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(&nn[1], right->d_n + frame, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  const int nL = nn[0], nR = nn[1];
+  if (n_left) *n_left = nL;
+  if (n_right) *n_right = nR;
+  *nmatches = 0;
+  if (rounds) *rounds = 0;
+  if (nL > cap_left || nR > cap_right) return ORBX_ERR_CAPACITY;
+  if ((nL > 0 && (!assigned_left || !left_to_right)) || (nR > 0 && (!assigned_right || !right_to_left)))
+    return ORBX_ERR_BAD_ARG;
+  for (int i = 0; i < nL; ++i)
+    if (left_to_right[i] < -1 || left_to_right[i] >= nR) return ORBX_ERR_BAD_ARG;
+  for (int i = 0; i < nR; ++i)
+    if (right_to_left[i] < -1 || right_to_left[i] >= nL) return ORBX_ERR_BAD_ARG;
+  for (int i = 0; i < nL; ++i) assigned_left[i] = -1;
+  for (int i = 0; i < nR; ++i) assigned_right[i] = -1;
+  if (n_points == 0 || (nL == 0 && nR == 0)) return ORBX_OK;
+  const size_t np = (size_t)n_points, nnl = (size_t)std::max(nL, 1), nnr = (size_t)std::max(nR, 1);
+  Carver c;
+  const size_t oView = c.add(np), oProj = c.add(np * 8), oLvl = c.add(np * 4), oCos = c.add(np * 4),
+               oViewR = c.add(np), oProjR = c.add(np * 8), oLvlR = c.add(np * 4), oCosR = c.add(np * 4),
+               oDesc = c.add(np * 32), oObs = c.add(np), oL2R = c.add(nnl * 4), oR2L = c.add(nnr * 4),
+               oStL = c.add(nnl), oStR = c.add(nnr),
+               oWork = c.add(orbx::points_rig_work_ints(n_points, nL, nR) * 4), oAsgL = c.add(nnl * 4),
+               oAsgR = c.add(nnr * 4), oSum = c.add(8);
+  uint8_t* d = nullptr;
+  hipError_t e = hipMallocAsync((void**)&d, c.total, s);
+  if (e != hipSuccess) { last_hip_error = e; return ORBX_ERR_HIP; }
+  PackedUpload pk;
+  if (!pk.init(oWork)) { (void)hipFreeAsync(d, s); return ORBX_ERR_UNSUPPORTED; }
+  auto up = [&](size_t off, const void* src, size_t bytes) { pk.add(off, src, bytes); };
+  up(oView, in_view, np); up(oProj, proj, np * 8); up(oLvl, level, np * 4); up(oCos, view_cos, np * 4);
+  up(oViewR, viewR.data(), np); up(oProjR, proj_right, np * 8); up(oLvlR, level_right, np * 4);
+  up(oCosR, view_cos_right, np * 4); up(oDesc, desc, np * 32); up(oObs, obs, np);
+  if (nL > 0) up(oL2R, left_to_right, (size_t)nL * 4);
+  if (nR > 0) up(oR2L, right_to_left, (size_t)nR * 4);
+  if (state_left && nL > 0) up(oStL, state_left, (size_t)nL);
+  if (state_right && nR > 0) up(oStR, state_right, (size_t)nR);
+  e = pk.send(d, s);
+  int sum[2] = {0, 0};
+  if (e == hipSuccess) {
+    const size_t bL = (size_t)frame * ex->hp.kp_cap, bR = (size_t)frame * right->hp.kp_cap;
+    orbx::launch_search_by_projection_points_rig(
+        d + oView, (const float*)(d + oProj), (const int*)(d + oLvl), (const float*)(d + oCos), d + oViewR,
+        (const float*)(d + oProjR), (const int*)(d + oLvlR), (const float*)(d + oCosR), d + oDesc, d + oObs, n_points,
+        ex->d_kpsUn + bL * 7, ex->d_desc + bL * 32, (state_left && nL > 0) ? d + oStL : nullptr, nL,
+        ex->d_cellStart + (size_t)frame * (ORBX_GRID_CELLS + 1), ex->d_cellEntries + bL, right->d_kpsUn + bR * 7,
+        right->d_desc + bR * 32, (state_right && nR > 0) ? d + oStR : nullptr, nR,
+        right->d_cellStart + (size_t)frame * (ORBX_GRID_CELLS + 1), right->d_cellEntries + bR,
+        (const int*)(d + oL2R), (const int*)(d + oR2L), ex->gridBounds, ex->scale.data(), ex->prm.nlevels, th,
+        nnratio, (int*)(d + oWork), (int*)(d + oAsgL), (int*)(d + oAsgR), (int*)(d + oSum), s);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess && nL > 0) e = hipMemcpyAsync(assigned_left, d + oAsgL, (size_t)nL * 4, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess && nR > 0) e = hipMemcpyAsync(assigned_right, d + oAsgR, (size_t)nR * 4, hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) e = hipMemcpyAsync(sum, d + oSum, 8, hipMemcpyDeviceToHost, s);
   {   // also after an error: the packed host block must outlive whatever was enqueued
     const hipError_t es = hipStreamSynchronize(s);

@@ -165,6 +165,15 @@ struct ProjectionArgs {
   int* assigned;           // n
   int* summary;            // [0] nmatches, [1] rounds
   int gathered;            // the candidate lists were filled by a gather launch before this one
+  // ---- the second camera of a rig (matcher.cc:1712-1786); all unset for one camera
+  // gate: the first camera's candCount array: a last-frame keypoint is searched in the second
+  // camera only if its search in the first one got as far as a non-empty window (:1624-1652)
+  const int* gate;
+  int skipBounds;          // the projection into the second camera is not checked against the image
+  // deferRotation: leave the rotation check to k_rig_rotation_finish (one histogram for both
+  // cameras); finalChoice[i] = the keypoint query i ended up with, or -1
+  int deferRotation;
+  int* finalChoice;
 };
 
 // choice of last-frame keypoint i given the closing times of the previous round
@@ -173,11 +182,14 @@ struct ProjectionArgs {
 __device__ int projection_choice(const ProjectionArgs& a, int i, const int* closedAt, bool store, bool decide = true) {
   if (store) a.candCount[i] = 0;
   if (!a.lastValid[i]) return -1;
+  if (a.gate && a.gate[i] == 0) return -1;
   const float invzc = a.invz[i];
   if (invzc < 0) return -1;
   const float u = a.uv[2 * i], v = a.uv[2 * i + 1];
-  if (u < a.grid.minX || u > a.grid.maxX) return -1;
-  if (v < a.grid.minY || v > a.grid.maxY) return -1;
+  if (!a.skipBounds) {
+    if (u < a.grid.minX || u > a.grid.maxX) return -1;
+    if (v < a.grid.minY || v > a.grid.maxY) return -1;
+  }
   const int nLastOctave = a.lastOctave[i];
   const float radius = __fmul_rn(a.th, a.scale[nLastOctave]);
   int minLevel, maxLevel;
@@ -284,14 +296,15 @@ __global__ __launch_bounds__(GUIDED_THREADS) void k_search_by_projection_last(Pr
     if (c >= 0) {
       atomicMax(&a.assigned[c], i);
       atomicAdd(&nmS, 1);
-      if (a.checkOrientation) {
+      if (a.checkOrientation && !a.deferRotation) {
         const int bin = rotation_bin(a.lastAngle[i], a.grid.U[c].angle);
         if (bin >= 0 && bin < HISTO_LENGTH) atomicAdd(&hist[bin], 1);
       }
     }
+    if (a.deferRotation) a.finalChoice[i] = c;
   }
   __syncthreads();
-  if (a.checkOrientation) {
+  if (a.checkOrientation && !a.deferRotation) {
     // matcher.cc:1788-1805: keypoints of every bin but the three largest lose their map point
     if (tid == 0) three_maxima(hist, HISTO_LENGTH, keep);
     __syncthreads();
@@ -308,6 +321,72 @@ __global__ __launch_bounds__(GUIDED_THREADS) void k_search_by_projection_last(Pr
     __syncthreads();
   }
   if (tid == 0) { a.summary[0] = nmS; a.summary[1] = rounds; }
+}
+
+// The rotation check of matcher.cc:1788-1805 over the matches of both cameras of a rig: one
+// histogram, the three largest bins kept, every entry of the other bins cleared (-2).
+// summary[0] = nmatches of both cameras after the check, summary[1] = the larger round count.
+struct RigFinishArgs {
+  int nLast;
+  const int* choiceL;
+  const int* choiceR;
+  const float* lastAngle;
+  const GKP* UL;
+  const GKP* UR;
+  int* assignedL;
+  int* assignedR;
+  const int* summaryL;
+  const int* summaryR;
+  int* summary;
+  int checkOrientation;
+};
+
+__global__ __launch_bounds__(GUIDED_THREADS) void k_rig_rotation_finish(RigFinishArgs a) {
+  __shared__ int hist[HISTO_LENGTH];
+  __shared__ int keep[3];
+  __shared__ int cleared;
+  const int tid = threadIdx.x;
+  if (tid < HISTO_LENGTH) hist[tid] = 0;
+  if (tid == 0) cleared = 0;
+  __syncthreads();
+  if (a.checkOrientation) {
+    for (int i = tid; i < a.nLast; i += GUIDED_THREADS) {
+      const int cl = a.choiceL[i], cr = a.choiceR[i];
+      if (cl >= 0) {
+        const int bin = rotation_bin(a.lastAngle[i], a.UL[cl].angle);
+        if (bin >= 0 && bin < HISTO_LENGTH) atomicAdd(&hist[bin], 1);
+      }
+      if (cr >= 0) {
+        const int bin = rotation_bin(a.lastAngle[i], a.UR[cr].angle);
+        if (bin >= 0 && bin < HISTO_LENGTH) atomicAdd(&hist[bin], 1);
+      }
+    }
+    __syncthreads();
+    if (tid == 0) three_maxima(hist, HISTO_LENGTH, keep);
+    __syncthreads();
+    for (int i = tid; i < a.nLast; i += GUIDED_THREADS) {
+      const int cl = a.choiceL[i], cr = a.choiceR[i];
+      if (cl >= 0) {
+        const int bin = rotation_bin(a.lastAngle[i], a.UL[cl].angle);
+        if (bin >= 0 && bin < HISTO_LENGTH && bin != keep[0] && bin != keep[1] && bin != keep[2]) {
+          a.assignedL[cl] = -2;
+          atomicAdd(&cleared, 1);
+        }
+      }
+      if (cr >= 0) {
+        const int bin = rotation_bin(a.lastAngle[i], a.UR[cr].angle);
+        if (bin >= 0 && bin < HISTO_LENGTH && bin != keep[0] && bin != keep[1] && bin != keep[2]) {
+          a.assignedR[cr] = -2;
+          atomicAdd(&cleared, 1);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    a.summary[0] = a.summaryL[0] + a.summaryR[0] - cleared;
+    a.summary[1] = max(a.summaryL[1], a.summaryR[1]);
+  }
 }
 
 struct PointsArgs {
@@ -358,13 +437,23 @@ struct BestTwo {
     if (bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(nnratio, (float)bestDist2)) return -1;
     return bestIdx;
   }
+  // the same with the two ways of failing told apart: -1 no candidate within TH_HIGH, -2 the
+  // ratio test failed (the `continue` of matcher.cc:123-124, which leaves the map point's loop body)
+  __device__ __forceinline__ int accepted3(float nnratio) const {
+    if (bestDist > TH_HIGH) return -1;
+    if (bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(nnratio, (float)bestDist2)) return -2;
+    return bestIdx;
+  }
 };
 
-// choice of map point i given the closing times of the previous round.  store: remember the
-// candidates.
-__device__ int points_choice(const PointsArgs& a, int i, const int* closedAt, bool store, bool decide = true) {
+// The candidates of map point i in window order (matcher.cc:64-118), each offered to `b` unless
+// closed(i2) says the keypoint holds a map point with observations (:89-91).  store: remember
+// the candidates.  decide = false only walks and stores.
+template <class Closed>
+__device__ __forceinline__ BestTwo points_walk(const PointsArgs& a, int i, Closed closed, bool store, bool decide) {
+  BestTwo b;
   if (store) a.candCount[i] = 0;
-  if (!a.inView[i]) return -1;
+  if (!a.inView[i]) return b;
   const int nPredictedLevel = a.level[i];
   // RadiusByViewingCos (matcher.cc:215-220; the comparison is made in double)
   float r = (double)a.viewCos[i] > 0.998 ? 2.5f : 4.0f;
@@ -373,8 +462,7 @@ __device__ int points_choice(const PointsArgs& a, int i, const int* closedAt, bo
   uint32_t dMP[8];
 #pragma unroll
   for (int w = 0; w < 8; ++w) dMP[w] = a.ptDesc[(size_t)i * 8 + w];
-  const float xr = a.projXR[i];
-  BestTwo b;
+  const float xr = a.uRight ? a.projXR[i] : 0.0f;
   int k = 0;
   for_each_in_area(a.grid, a.proj[2 * i], a.proj[2 * i + 1], radius, nPredictedLevel - 1, nPredictedLevel, [&](int i2) {
     if (a.uRight) {
@@ -391,22 +479,33 @@ __device__ int points_choice(const PointsArgs& a, int i, const int* closedAt, bo
         a.cand[(size_t)k * a.nPts + i] = ((uint32_t)dist << 20) | ((uint32_t)octave << 16) | (uint32_t)i2;
       ++k;
     }
-    if (!decide || coherent_load(&closedAt[i2]) < i) return;   // holds a map point with observations (:89-91)
+    if (!decide || closed(i2)) return;
     b.consider(i2, dist, octave);
   });
   if (store) a.candCount[i] = k <= GUIDED_CACHE ? k : -1;
-  return b.accepted(a.nnratio);
+  return b;
 }
 
-__device__ int points_choice_cached(const PointsArgs& a, int i, const int* closedAt, int cnt) {
+// the same from the remembered candidates (same order, so the same ties)
+template <class Closed>
+__device__ __forceinline__ BestTwo points_walk_cached(const PointsArgs& a, int i, Closed closed, int cnt) {
   BestTwo b;
   for (int k = 0; k < cnt; ++k) {
     const uint32_t e = a.cand[(size_t)k * a.nPts + i];
     const int i2 = (int)(e & 0xFFFFu);
-    if (coherent_load(&closedAt[i2]) < i) continue;
+    if (closed(i2)) continue;
     b.consider(i2, (int)(e >> 20), (int)((e >> 16) & 0xFu));
   }
-  return b.accepted(a.nnratio);
+  return b;
+}
+
+// choice of map point i given the closing times of the previous round
+__device__ int points_choice(const PointsArgs& a, int i, const int* closedAt, bool store, bool decide = true) {
+  return points_walk(a, i, [&](int i2) { return coherent_load(&closedAt[i2]) < i; }, store, decide).accepted(a.nnratio);
+}
+
+__device__ int points_choice_cached(const PointsArgs& a, int i, const int* closedAt, int cnt) {
+  return points_walk_cached(a, i, [&](int i2) { return coherent_load(&closedAt[i2]) < i; }, cnt).accepted(a.nnratio);
 }
 
 __global__ __launch_bounds__(GATHER_THREADS) void k_gather_points(PointsArgs a) {
@@ -464,6 +563,115 @@ __global__ __launch_bounds__(GUIDED_THREADS) void k_search_by_projection_points(
       atomicAdd(&nmS, 1);
     }
   }
+  __syncthreads();
+  if (tid == 0) { a.summary[0] = nmS; a.summary[1] = rounds; }
+}
+
+// ORBmatcher::SearchByProjection(F, vpMapPoints, th) for a frame with two cameras (F.Nleft != -1,
+// matcher.cc:41-213).  Map point i takes two steps, the left camera's search at time 2i and the
+// right camera's at time 2i + 1; a step that matches keypoint c writes the map point into c and
+// into c's stereo partner in the other camera (:129-135, :197-203), whatever either held before.
+// A keypoint is closed to a step at time t when the LATEST write before t put a map point with
+// observations there (no write yet: its initial state) - a partner write of a point without
+// observations re-opens a keypoint, so a closing time per keypoint is not enough: every keypoint
+// keeps the list of the writes of the previous round, and a step looks for the latest one before
+// its own time.  Rounds repeat until no step changes its choice; a step at time t depends only on
+// steps before t, so round r has every step before time r right and the fixed point is the
+// sequential loop's result.
+//   write node 4i + k:  k = 0 left keypoint, by the left step;   1 its partner in the right camera;
+//                       k = 2 right keypoint, by the right step;  3 its partner in the left camera
+struct RigPointsArgs {
+  PointsArgs cam[2];        // per camera; cam[1].inView: in the right view AND with a predicted level
+                            // there (:144-146), cam[1].th = 1 (the right radius ignores th, :147)
+  const int* partner[2];    // [0] mvLeftToRightMatch (nL entries), [1] mvRightToLeftMatch (nR); -1 none
+  int* choice[2][2];        // [generation][camera], nPts each: keypoint, -1 none, -2 ratio test failed
+  int* head[2];             // per camera, n each: latest pushed write node, -1 none
+  int* next;                // 4 nPts
+  int* assigned[2];
+  int* summary;             // [0] nmatches, [1] rounds
+};
+
+__device__ __forceinline__ int rig_node_time(int node) { return 2 * (node >> 2) + ((node & 3) >> 1); }
+
+// whether keypoint k of a camera holds a map point with observations just before time t
+__device__ __forceinline__ bool rig_closed(const int* head, const int* next, const uint8_t* state,
+                                           const uint8_t* ptObs, int k, int t) {
+  int latest = -1, latestT = -1;
+  for (int node = coherent_load(&head[k]); node >= 0; node = coherent_load(&next[node])) {
+    const int tn = rig_node_time(node);
+    if (tn < t && tn > latestT) { latestT = tn; latest = node; }
+  }
+  if (latest < 0) return state && state[k] == 1;
+  return ptObs[latest >> 2] != 0;
+}
+
+__device__ __forceinline__ void rig_push(int* head, int* next, int k, int node) {
+  next[node] = atomicExch(&head[k], node);
+}
+
+__global__ __launch_bounds__(GUIDED_THREADS) void k_search_by_projection_points_rig(RigPointsArgs a) {
+  __shared__ int nmS;
+  const int tid = threadIdx.x;
+  const int nPts = a.cam[0].nPts;
+  const uint8_t* ptObs = a.cam[0].ptObs;
+  for (int i = tid; i < nPts; i += GUIDED_THREADS) { a.choice[0][0][i] = -1; a.choice[0][1][i] = -1; }
+  if (tid == 0) nmS = 0;
+  __syncthreads();
+  int cur = 0, rounds = 0;
+  for (;;) {
+    // the writes of the previous round's choices, per keypoint
+    for (int cam = 0; cam < 2; ++cam)
+      for (int k = tid; k < a.cam[cam].n; k += GUIDED_THREADS) a.head[cam][k] = -1;
+    __syncthreads();
+    for (int i = tid; i < nPts; i += GUIDED_THREADS) {
+      const int cl = coherent_load(&a.choice[cur][0][i]), cr = coherent_load(&a.choice[cur][1][i]);
+      if (cl >= 0) {
+        rig_push(a.head[0], a.next, cl, 4 * i);
+        const int p = a.partner[0][cl];
+        if (p >= 0) rig_push(a.head[1], a.next, p, 4 * i + 1);
+      }
+      if (cr >= 0) {
+        rig_push(a.head[1], a.next, cr, 4 * i + 2);
+        const int p = a.partner[1][cr];
+        if (p >= 0) rig_push(a.head[0], a.next, p, 4 * i + 3);
+      }
+    }
+    __syncthreads();
+    int changed = 0;
+    for (int i = tid; i < nPts; i += GUIDED_THREADS) {
+      int c[2];
+      for (int cam = 0; cam < 2; ++cam) {
+        const PointsArgs& pa = a.cam[cam];
+        if (cam == 1 && c[0] == -2) { c[1] = -1; break; }   // :123-124 skips the right camera too
+        const int t = 2 * i + cam;
+        auto closed = [&](int i2) { return rig_closed(a.head[cam], a.next, pa.state, ptObs, i2, t); };
+        const int cnt = pa.candCount[i];
+        const BestTwo b = cnt >= 0 ? points_walk_cached(pa, i, closed, cnt) : points_walk(pa, i, closed, false, true);
+        c[cam] = b.accepted3(pa.nnratio);
+      }
+      for (int cam = 0; cam < 2; ++cam) {
+        changed |= (c[cam] != coherent_load(&a.choice[cur][cam][i])) ? 1 : 0;
+        a.choice[cur ^ 1][cam][i] = c[cam];
+      }
+    }
+    ++rounds;
+    cur ^= 1;
+    const int any = __syncthreads_or(changed);
+    if (!any || rounds > 2 * nPts + 2) break;
+  }
+  // nothing changed in the last round: the lists hold exactly the final choices' writes.  A
+  // keypoint keeps the map point of its latest write; every write counts (:132-138, :200-207)
+  for (int cam = 0; cam < 2; ++cam)
+    for (int k = tid; k < a.cam[cam].n; k += GUIDED_THREADS) {
+      int latest = -1, latestT = -1, cnt = 0;
+      for (int node = coherent_load(&a.head[cam][k]); node >= 0; node = coherent_load(&a.next[node])) {
+        const int tn = rig_node_time(node);
+        if (tn > latestT) { latestT = tn; latest = node; }
+        ++cnt;
+      }
+      a.assigned[cam][k] = latest >= 0 ? (latest >> 2) : -1;
+      if (cnt) atomicAdd(&nmS, cnt);
+    }
   __syncthreads();
   if (tid == 0) { a.summary[0] = nmS; a.summary[1] = rounds; }
 }
@@ -792,11 +1000,71 @@ void launch_search_by_projection_last(const uint8_t* d_lastValid, const float* d
   a.candCount = a.closedAt[1] + n;
   a.cand = (uint32_t*)(a.candCount + nLast);
   a.assigned = d_assigned; a.summary = d_summary;
+  a.gate = nullptr; a.skipBounds = 0; a.deferRotation = 0; a.finalChoice = nullptr;
   a.gathered = gather_first(nLast);
   if (a.gathered)
     hipLaunchKernelGGL(k_gather_projection, dim3((nLast + GATHER_THREADS - 1) / GATHER_THREADS), dim3(GATHER_THREADS), 0,
                        s, a);
   hipLaunchKernelGGL(k_search_by_projection_last, dim3(1), dim3(GUIDED_THREADS), 0, s, a);
+}
+
+// The two cameras of a rig (matcher.cc:1591-1808 with CurrentFrame.Nleft != -1): the left camera's
+// search, the right camera's search gated by the left one's candidate counts, and one rotation
+// check over both.  d_workL / d_workR: projection_work_ints(nLast, nL / nR) + nLast ints each
+// (the extra nLast hold the final choices); d_sumL / d_sumR: 2 ints each.
+void launch_search_by_projection_last_rig(const uint8_t* d_lastValid, const float* d_uvL, const float* d_invz,
+                                          const float* d_uvR, const int* d_lastOctave, const float* d_lastAngle,
+                                          const uint8_t* d_lastDesc, const uint8_t* d_lastObs, int nLast,
+                                          const float* d_kpsL, const uint8_t* d_descL, const uint8_t* d_stateL, int nL,
+                                          const int* d_cellStartL, const int* d_entriesL, const float* d_kpsR,
+                                          const uint8_t* d_descR, const uint8_t* d_stateR, int nR,
+                                          const int* d_cellStartR, const int* d_entriesR, const float* bounds,
+                                          const float* scaleFactors, int nlevels, float th, int forward, int backward,
+                                          int checkOrientation, int* d_workL, int* d_workR, int* d_assignedL,
+                                          int* d_assignedR, int* d_sumL, int* d_sumR, int* d_summary, hipStream_t s) {
+  ProjectionArgs a;
+  a.maxDist = TH_HIGH;
+  a.lastValid = d_lastValid; a.invz = d_invz; a.lastOctave = d_lastOctave;
+  a.lastAngle = d_lastAngle; a.lastDesc = (const uint32_t*)d_lastDesc; a.lastObs = d_lastObs; a.nLast = nLast;
+  a.uRight = nullptr;   // the mvuRight test needs a frame with one camera (:1669)
+  for (int l = 0; l < ORBX_MAX_LEVELS; ++l) a.scale[l] = l < nlevels ? scaleFactors[l] : 1.0f;
+  a.th = th; a.mbf = 0.0f; a.forward = forward; a.backward = backward; a.checkOrientation = checkOrientation;
+  a.deferRotation = 1;
+  a.gathered = gather_first(nLast);
+  const int* candCountL = nullptr;
+  for (int cam = 0; cam < 2; ++cam) {
+    int* w = cam == 0 ? d_workL : d_workR;
+    const int n = cam == 0 ? nL : nR;
+    a.uv = cam == 0 ? d_uvL : d_uvR;
+    a.grid = cam == 0 ? make_grid(d_kpsL, d_cellStartL, d_entriesL, bounds) : make_grid(d_kpsR, d_cellStartR, d_entriesR, bounds);
+    a.desc = (const uint32_t*)(cam == 0 ? d_descL : d_descR);
+    a.state = cam == 0 ? d_stateL : d_stateR;
+    a.n = n;
+    a.choice[0] = w; a.choice[1] = w + nLast;
+    a.closedAt[0] = w + 2 * (size_t)nLast; a.closedAt[1] = a.closedAt[0] + n;
+    a.candCount = a.closedAt[1] + n;
+    a.cand = (uint32_t*)(a.candCount + nLast);
+    a.finalChoice = w + projection_work_ints(nLast, n);
+    a.assigned = cam == 0 ? d_assignedL : d_assignedR;
+    a.summary = cam == 0 ? d_sumL : d_sumR;
+    a.gate = cam == 0 ? nullptr : candCountL;
+    a.skipBounds = cam;
+    if (cam == 0) candCountL = a.candCount;
+    if (a.gathered)
+      hipLaunchKernelGGL(k_gather_projection, dim3((nLast + GATHER_THREADS - 1) / GATHER_THREADS), dim3(GATHER_THREADS),
+                         0, s, a);
+    hipLaunchKernelGGL(k_search_by_projection_last, dim3(1), dim3(GUIDED_THREADS), 0, s, a);
+  }
+  RigFinishArgs f;
+  f.nLast = nLast;
+  f.choiceL = d_workL + projection_work_ints(nLast, nL);
+  f.choiceR = d_workR + projection_work_ints(nLast, nR);
+  f.lastAngle = d_lastAngle;
+  f.UL = (const GKP*)d_kpsL; f.UR = (const GKP*)d_kpsR;
+  f.assignedL = d_assignedL; f.assignedR = d_assignedR;
+  f.summaryL = d_sumL; f.summaryR = d_sumR; f.summary = d_summary;
+  f.checkOrientation = checkOrientation;
+  hipLaunchKernelGGL(k_rig_rotation_finish, dim3(1), dim3(GUIDED_THREADS), 0, s, f);
 }
 
 void launch_search_by_projection_points(const uint8_t* d_inView, const float* d_proj, const float* d_projXR,
@@ -823,6 +1091,60 @@ void launch_search_by_projection_points(const uint8_t* d_inView, const float* d_
   if (a.gathered)
     hipLaunchKernelGGL(k_gather_points, dim3((nPts + GATHER_THREADS - 1) / GATHER_THREADS), dim3(GATHER_THREADS), 0, s, a);
   hipLaunchKernelGGL(k_search_by_projection_points, dim3(1), dim3(GUIDED_THREADS), 0, s, a);
+}
+
+// work memory of the two-camera form, in ints: per camera the candidate lists and counts and two
+// generations of choices, the write lists (heads per keypoint, 4 nodes per map point)
+size_t points_rig_work_ints(int nPts, int nL, int nR) {
+  return (size_t)nPts * (2 * (GUIDED_CACHE + 1) + 4 + 4) + (size_t)nL + (size_t)nR;
+}
+
+// d_inViewR: in the right camera's view and with a predicted level there (the caller folds
+// mnTrackScaleLevelR != -1 in, so that no level of -1 reaches the scale table)
+void launch_search_by_projection_points_rig(const uint8_t* d_inView, const float* d_proj, const int* d_level,
+                                            const float* d_viewCos, const uint8_t* d_inViewR, const float* d_projR,
+                                            const int* d_levelR, const float* d_viewCosR, const uint8_t* d_ptDesc,
+                                            const uint8_t* d_ptObs, int nPts, const float* d_kpsL,
+                                            const uint8_t* d_descL, const uint8_t* d_stateL, int nL,
+                                            const int* d_cellStartL, const int* d_entriesL, const float* d_kpsR,
+                                            const uint8_t* d_descR, const uint8_t* d_stateR, int nR,
+                                            const int* d_cellStartR, const int* d_entriesR, const int* d_leftToRight,
+                                            const int* d_rightToLeft, const float* bounds, const float* scaleFactors,
+                                            int nlevels, float th, float nnratio, int* d_work, int* d_assignedL,
+                                            int* d_assignedR, int* d_summary, hipStream_t s) {
+  RigPointsArgs a;
+  int* w = d_work;
+  auto take = [&](size_t ints) { int* p = w; w += ints; return p; };
+  for (int cam = 0; cam < 2; ++cam) {
+    PointsArgs& p = a.cam[cam];
+    p.inView = cam == 0 ? d_inView : d_inViewR;
+    p.proj = cam == 0 ? d_proj : d_projR;
+    p.projXR = nullptr;
+    p.level = cam == 0 ? d_level : d_levelR;
+    p.viewCos = cam == 0 ? d_viewCos : d_viewCosR;
+    p.ptDesc = (const uint32_t*)d_ptDesc; p.ptObs = d_ptObs; p.nPts = nPts;
+    p.grid = cam == 0 ? make_grid(d_kpsL, d_cellStartL, d_entriesL, bounds) : make_grid(d_kpsR, d_cellStartR, d_entriesR, bounds);
+    p.desc = (const uint32_t*)(cam == 0 ? d_descL : d_descR);
+    p.uRight = nullptr;   // the mvuRight test needs a frame with one camera (:93)
+    p.state = cam == 0 ? d_stateL : d_stateR;
+    p.n = cam == 0 ? nL : nR;
+    for (int l = 0; l < ORBX_MAX_LEVELS; ++l) p.scale[l] = l < nlevels ? scaleFactors[l] : 1.0f;
+    p.th = cam == 0 ? th : 1.0f;
+    p.nnratio = nnratio;
+    p.choice[0] = p.choice[1] = nullptr; p.closedAt[0] = p.closedAt[1] = nullptr;
+    p.candCount = take(nPts);
+    p.cand = (uint32_t*)take((size_t)GUIDED_CACHE * nPts);
+    p.assigned = nullptr; p.summary = nullptr; p.gathered = 1;
+    a.choice[0][cam] = take(nPts);
+    a.choice[1][cam] = take(nPts);
+    a.head[cam] = take(p.n);
+    hipLaunchKernelGGL(k_gather_points, dim3((nPts + GATHER_THREADS - 1) / GATHER_THREADS), dim3(GATHER_THREADS), 0, s, p);
+  }
+  a.next = take(4 * (size_t)nPts);
+  a.partner[0] = d_leftToRight; a.partner[1] = d_rightToLeft;
+  a.assigned[0] = d_assignedL; a.assigned[1] = d_assignedR;
+  a.summary = d_summary;
+  hipLaunchKernelGGL(k_search_by_projection_points_rig, dim3(1), dim3(GUIDED_THREADS), 0, s, a);
 }
 
 void launch_search_by_bow(const uint8_t* d_kfValid, const float* d_kfAngle, const uint8_t* d_kfDesc, int nKfNodes,

@@ -44,6 +44,77 @@ def search_by_projection_last(ex, frame, last_valid, uv, invz, last_octave, last
     return nm.value, out[:n.value].copy(), rounds.value
 
 
+def search_by_projection_last_rig(left, right, frame, last_valid, uv_left, invz, uv_right, last_octave, last_angle,
+                                  last_desc, last_obs, state_left=None, state_right=None, th=15.0, forward=False,
+                                  backward=False, check_orientation=True):
+    """The same matcher when the current frame has two cameras (CurrentFrame.Nleft != -1,
+    matcher.cc:1591-1808 with the right camera's pass of :1712-1786) -> (nmatches,
+    assigned_left[nL], assigned_right[nR], rounds).  left / right: the ORBextractors holding the
+    two cameras' keypoints and grids for `frame`; the reference's index i2 >= Nleft is right
+    keypoint i2 - Nleft."""
+    lv = np.ascontiguousarray(last_valid, np.uint8)
+    n_last = len(lv)
+    ul = np.ascontiguousarray(uv_left, np.float32).reshape(-1, 2)
+    ur = np.ascontiguousarray(uv_right, np.float32).reshape(-1, 2)
+    iz = np.ascontiguousarray(invz, np.float32)
+    lo = np.ascontiguousarray(last_octave, np.int32)
+    la = np.ascontiguousarray(last_angle, np.float32)
+    ld = np.ascontiguousarray(last_desc, np.uint8).reshape(-1, 32)
+    lobs = np.ascontiguousarray(last_obs, np.uint8)
+    assert len(ul) == len(ur) == len(iz) == len(lo) == len(la) == len(ld) == len(lobs) == n_last
+    cap_l, cap_r = left.max_keypoints(), right.max_keypoints()
+    sl = None if state_left is None else np.ascontiguousarray(state_left, np.uint8)
+    sr = None if state_right is None else np.ascontiguousarray(state_right, np.uint8)
+    out_l, out_r = np.zeros(cap_l, np.int32), np.zeros(cap_r, np.int32)
+    nl, nr, nm, rounds = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    check(lib().orbx_search_by_projection_last_rig(
+        left._h, right._h, int(frame), n_last, ptr(lv), ul.ctypes.data_as(_f32p), iz.ctypes.data_as(_f32p),
+        ur.ctypes.data_as(_f32p), lo.ctypes.data_as(_i32p), la.ctypes.data_as(_f32p), ptr(ld), ptr(lobs), ptr(sl),
+        ptr(sr), float(th), int(bool(forward)), int(bool(backward)), int(bool(check_orientation)), ptr(out_l), cap_l,
+        C.byref(nl), ptr(out_r), cap_r, C.byref(nr), C.byref(nm), C.byref(rounds)),
+        "orbx_search_by_projection_last_rig")
+    for st, n in ((sl, nl.value), (sr, nr.value)):
+        if st is not None:
+            assert len(st) >= n
+    return nm.value, out_l[:nl.value].copy(), out_r[:nr.value].copy(), rounds.value
+
+
+def search_by_projection_points_rig(left, right, frame, in_view, proj, level, view_cos, in_view_right, proj_right,
+                                    level_right, view_cos_right, desc, obs, left_to_right, right_to_left,
+                                    state_left=None, state_right=None, th=1.0, nnratio=0.8):
+    """ORBmatcher::SearchByProjection(F, vpMapPoints, th) for a frame with two cameras (F.Nleft != -1,
+    matcher.cc:41-213) -> (nmatches, assigned_left[nL], assigned_right[nR], rounds).  left_to_right /
+    right_to_left: mvLeftToRightMatch / mvRightToLeftMatch in each camera's own numbering."""
+    iv = np.ascontiguousarray(in_view, np.uint8)
+    n_pts = len(iv)
+    pj = np.ascontiguousarray(proj, np.float32).reshape(-1, 2)
+    lv = np.ascontiguousarray(level, np.int32)
+    vc = np.ascontiguousarray(view_cos, np.float32)
+    ivr = np.ascontiguousarray(in_view_right, np.uint8)
+    pjr = np.ascontiguousarray(proj_right, np.float32).reshape(-1, 2)
+    lvr = np.ascontiguousarray(level_right, np.int32)
+    vcr = np.ascontiguousarray(view_cos_right, np.float32)
+    pd = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    po = np.ascontiguousarray(obs, np.uint8)
+    assert len(pj) == len(lv) == len(vc) == len(ivr) == len(pjr) == len(lvr) == len(vcr) == len(pd) == len(po) == n_pts
+    l2r = np.ascontiguousarray(left_to_right, np.int32)
+    r2l = np.ascontiguousarray(right_to_left, np.int32)
+    cap_l, cap_r = left.max_keypoints(), right.max_keypoints()
+    sl = None if state_left is None else np.ascontiguousarray(state_left, np.uint8)
+    sr = None if state_right is None else np.ascontiguousarray(state_right, np.uint8)
+    out_l, out_r = np.zeros(cap_l, np.int32), np.zeros(cap_r, np.int32)
+    nl, nr, nm, rounds = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    check(lib().orbx_search_by_projection_points_rig(
+        left._h, right._h, int(frame), n_pts, ptr(iv), pj.ctypes.data_as(_f32p), lv.ctypes.data_as(_i32p),
+        vc.ctypes.data_as(_f32p), ptr(ivr), pjr.ctypes.data_as(_f32p), lvr.ctypes.data_as(_i32p),
+        vcr.ctypes.data_as(_f32p), ptr(pd), ptr(po), l2r.ctypes.data_as(_i32p) if len(l2r) else None,
+        r2l.ctypes.data_as(_i32p) if len(r2l) else None, ptr(sl), ptr(sr), float(th), float(nnratio), ptr(out_l),
+        cap_l, C.byref(nl), ptr(out_r), cap_r, C.byref(nr), C.byref(nm), C.byref(rounds)),
+        "orbx_search_by_projection_points_rig")
+    assert len(l2r) >= nl.value and len(r2l) >= nr.value
+    return nm.value, out_l[:nl.value].copy(), out_r[:nr.value].copy(), rounds.value
+
+
 def search_by_projection_points(ex, frame, in_view, proj, proj_xr, level, view_cos, desc, obs, u_right=None,
                                 state=None, th=1.0, nnratio=0.8):
     """ORBmatcher::SearchByProjection(F, vpMapPoints, th) (matcher.cc:41-142) -> (nmatches,

@@ -59,6 +59,11 @@ def lib():
             [C.c_void_p] * 4 + [C.c_float, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]
         L.orc_search_by_projection_points.argtypes = [C.c_void_p] * 7 + [C.c_int] + [C.c_void_p] * 4 + [C.c_int] + \
             [C.c_void_p] * 4 + [C.c_float, C.c_float, C.c_void_p]
+        L.orc_search_by_projection_last_rig.argtypes = [C.c_void_p] * 8 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] + \
+            [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 4 + [C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                                             C.c_void_p]
+        L.orc_search_by_projection_points_rig.argtypes = [C.c_void_p] * 10 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] + \
+            [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 6 + [C.c_float, C.c_float, C.c_void_p, C.c_void_p]
         L.orc_stereo_from_rgbd.restype = None
         L.orc_stereo_from_rgbd.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p,
                                            C.c_void_p]
@@ -337,6 +342,70 @@ def search_by_projection_points(in_view, proj, proj_xr, level, view_cos, pt_desc
                                               _p(k), _p(d), _p(ur) if ur is not None else None, _p(st), len(k),
                                               _p(b), _p(cs), _p(ent), _p(sf), th, nnratio, _p(out))
     return n, out[:len(k)]
+
+
+def _camera(k, d, state, cs, ent):
+    k = np.ascontiguousarray(k, KP)
+    d = np.ascontiguousarray(d if len(d) else np.zeros((1, 32)), np.uint8)
+    st = np.ascontiguousarray(state if len(state) else np.zeros(1), np.uint8)
+    cs = np.ascontiguousarray(cs, np.int32)
+    ent = np.ascontiguousarray(ent if len(ent) else np.zeros(1), np.int32)
+    return k, d, st, cs, ent
+
+
+def search_by_projection_last_rig(last_valid, uv_left, invz, uv_right, last_octave, last_angle, last_desc, last_obs,
+                                  left, right, bounds, scale_factors, th, forward, backward,
+                                  check_orientation=True):
+    """left / right: (keypoints, descriptors, state, cellStart, entries) of the two cameras."""
+    lv = np.ascontiguousarray(last_valid, np.uint8)
+    ul = np.ascontiguousarray(uv_left, np.float32)
+    ur = np.ascontiguousarray(uv_right, np.float32)
+    iz = np.ascontiguousarray(invz, np.float32)
+    lo = np.ascontiguousarray(last_octave, np.int32)
+    la = np.ascontiguousarray(last_angle, np.float32)
+    ld = np.ascontiguousarray(last_desc, np.uint8)
+    lobs = np.ascontiguousarray(last_obs, np.uint8)
+    kl, dl, sl, csl, el = _camera(*left)
+    kr, dr, sr, csr, er = _camera(*right)
+    b = np.ascontiguousarray(bounds, np.float32)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    out_l = np.zeros(max(len(kl), 1), np.int32)
+    out_r = np.zeros(max(len(kr), 1), np.int32)
+    n = lib().orc_search_by_projection_last_rig(_p(lv), _p(ul), _p(iz), _p(ur), _p(lo), _p(la), _p(ld), _p(lobs),
+                                                len(lv), _p(kl), _p(dl), _p(sl), len(kl), _p(csl), _p(el), _p(kr),
+                                                _p(dr), _p(sr), len(kr), _p(csr), _p(er), _p(b), _p(sf), th,
+                                                int(forward), int(backward), int(check_orientation), _p(out_l),
+                                                _p(out_r))
+    return n, out_l[:len(kl)], out_r[:len(kr)]
+
+
+def search_by_projection_points_rig(in_view, proj, level, view_cos, in_view_r, proj_r, level_r, view_cos_r, pt_desc,
+                                    pt_obs, left, right, left_to_right, right_to_left, bounds, scale_factors, th,
+                                    nnratio):
+    """left / right: (keypoints, descriptors, state, cellStart, entries) of the two cameras."""
+    iv = np.ascontiguousarray(in_view, np.uint8)
+    pj = np.ascontiguousarray(proj, np.float32)
+    lv = np.ascontiguousarray(level, np.int32)
+    vc = np.ascontiguousarray(view_cos, np.float32)
+    ivr = np.ascontiguousarray(in_view_r, np.uint8)
+    pjr = np.ascontiguousarray(proj_r, np.float32)
+    lvr = np.ascontiguousarray(level_r, np.int32)
+    vcr = np.ascontiguousarray(view_cos_r, np.float32)
+    pd = np.ascontiguousarray(pt_desc, np.uint8)
+    po = np.ascontiguousarray(pt_obs, np.uint8)
+    kl, dl, sl, csl, el = _camera(*left)
+    kr, dr, sr, csr, er = _camera(*right)
+    l2r = np.ascontiguousarray(left_to_right if len(left_to_right) else -np.ones(1), np.int32)
+    r2l = np.ascontiguousarray(right_to_left if len(right_to_left) else -np.ones(1), np.int32)
+    b = np.ascontiguousarray(bounds, np.float32)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    out_l = np.zeros(max(len(kl), 1), np.int32)
+    out_r = np.zeros(max(len(kr), 1), np.int32)
+    n = lib().orc_search_by_projection_points_rig(_p(iv), _p(pj), _p(lv), _p(vc), _p(ivr), _p(pjr), _p(lvr), _p(vcr),
+                                                  _p(pd), _p(po), len(iv), _p(kl), _p(dl), _p(sl), len(kl), _p(csl),
+                                                  _p(el), _p(kr), _p(dr), _p(sr), len(kr), _p(csr), _p(er), _p(l2r),
+                                                  _p(r2l), _p(b), _p(sf), th, nnratio, _p(out_l), _p(out_r))
+    return n, out_l[:len(kl)], out_r[:len(kr)]
 
 
 def stereo_from_rgbd(kps, kps_un, depth_img, mbf):

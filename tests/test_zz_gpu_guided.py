@@ -85,6 +85,137 @@ def test_search_by_projection_contention(oracle):
         assert rounds <= n_last + 2
 
 
+def rig_frames(w=512, h=512, shift_l=6, shift_r=-9, params=PARAMS, seed=47):
+    """A last frame a and the current frame's two cameras, each a shifted view of the same
+    texture: left(x) = a(x - shift_l), right(x) = a(x - shift_r)."""
+    pad = 16
+    wide = orbx.textured_frame(seed, w + 2 * pad, h)
+    a = np.ascontiguousarray(wide[:, pad:pad + w])
+    exa = orbx.ORBextractor(*params)
+    _, ka, da = exa(a, None, (0, 0))
+    bounds = grid.image_bounds(None, w, h)
+    cams = []
+    for sh in (shift_l, shift_r):
+        img = np.ascontiguousarray(wide[:, pad - sh:pad - sh + w])
+        ex = orbx.ORBextractor(*params)
+        _, k, d = ex(img, None, (0, 0))
+        grid.frame_grid_batch(ex, 1, None, bounds)
+        un, cs, ent = grid.frame_grid_download(ex, 0)
+        cams.append((ex, un, d, cs, ent))
+    return ka, da, cams, bounds
+
+
+@pytest.mark.parametrize("forward,backward,th,jitter", [(0, 0, 15.0, 2.0), (1, 0, 15.0, 2.0), (0, 1, 7.0, 2.0),
+                                                         (0, 0, 40.0, 6.0)])
+def test_search_by_projection_last_rig_matches_oracle(oracle, forward, backward, th, jitter):
+    """Two-camera current frame (CurrentFrame.Nleft != -1): the right camera's search is gated by
+    the left one's, both feed one rotation histogram."""
+    ka, da, cams, bounds = rig_frames()
+    (exl, kl, dl, csl, el), (exr, kr, dr, csr, er) = cams
+    rng = np.random.default_rng(11)
+    n_last = len(ka)
+    uvl = np.stack([ka["x"] + 6 + rng.uniform(-jitter, jitter, n_last),
+                    ka["y"] + rng.uniform(-jitter, jitter, n_last)], 1).astype(np.float32)
+    uvr = np.stack([ka["x"] - 9 + rng.uniform(-jitter, jitter, n_last),
+                    ka["y"] + rng.uniform(-jitter, jitter, n_last)], 1).astype(np.float32)
+    uvl[::17] += 700                     # left projection outside: the right camera is not searched either
+    uvr[::13] -= 600                     # right projection outside the image: not checked, its window is just empty
+    invz = rng.uniform(0.05, 1.0, n_last).astype(np.float32)
+    invz[::23] = -0.1
+    valid = (rng.random(n_last) < 0.9).astype(np.uint8)
+    obs = (rng.random(n_last) < 0.7).astype(np.uint8)
+    sl = rng.choice([0, 0, 0, 1, 2], len(kl)).astype(np.uint8)
+    sr = rng.choice([0, 0, 0, 1, 2], len(kr)).astype(np.uint8)
+    sf = np.array(exl.GetScaleFactors(), np.float32)
+    for ori in (True, False):
+        want_n, want_l, want_r = oracle.search_by_projection_last_rig(
+            valid, uvl, invz, uvr, ka["octave"], ka["angle"], da, obs, (kl, dl, sl, csl, el), (kr, dr, sr, csr, er),
+            bounds, sf, th, forward, backward, ori)
+        n, al, ar, rounds = guided.search_by_projection_last_rig(exl, exr, 0, valid, uvl, invz, uvr, ka["octave"],
+                                                                 ka["angle"], da, obs, sl, sr, th, forward, backward,
+                                                                 ori)
+        assert n == want_n and np.array_equal(al, want_l) and np.array_equal(ar, want_r), (forward, backward, ori)
+        assert 1 <= rounds <= 24, rounds
+        assert (al >= 0).sum() > 100 and (ar >= 0).sum() > 100
+    # without states, and with an empty right camera window everywhere
+    want_n, want_l, want_r = oracle.search_by_projection_last_rig(
+        valid, uvl, invz, uvr - 5000, ka["octave"], ka["angle"], da, obs, (kl, dl, sl * 0, csl, el),
+        (kr, dr, sr * 0, csr, er), bounds, sf, th, forward, backward, True)
+    n, al, ar, rounds = guided.search_by_projection_last_rig(exl, exr, 0, valid, uvl, invz, uvr - 5000, ka["octave"],
+                                                             ka["angle"], da, obs, None, None, th, forward, backward)
+    assert n == want_n and np.array_equal(al, want_l) and np.array_equal(ar, want_r) and (ar == -1).all()
+
+
+def stereo_partners(kl, kr, disparity, rng, random_share=0.0):
+    """mvLeftToRightMatch / mvRightToLeftMatch stand-ins: mutual links between keypoints of the two
+    cameras that sit `disparity` apart on the same row and level; a share of extra one-way links
+    to arbitrary keypoints exercises writes that the reference's code allows but its stereo
+    matcher would not produce."""
+    l2r = -np.ones(len(kl), np.int32)
+    r2l = -np.ones(len(kr), np.int32)
+    for i in range(len(kl)):
+        d = np.abs(kr["x"] - (kl["x"][i] - disparity)) + np.abs(kr["y"] - kl["y"][i]) + 100.0 * (kr["octave"] != kl["octave"][i])
+        j = int(np.argmin(d))
+        if d[j] <= 1.5 and r2l[j] < 0:
+            l2r[i], r2l[j] = j, i
+    extra_l = rng.random(len(kl)) < random_share
+    l2r[extra_l] = rng.integers(0, len(kr), extra_l.sum())
+    extra_r = rng.random(len(kr)) < random_share
+    r2l[extra_r] = rng.integers(0, len(kl), extra_r.sum())
+    return l2r, r2l
+
+
+@pytest.mark.parametrize("th,nnratio,random_share,obs_p", [(1.0, 0.8, 0.0, 0.7), (3.0, 0.8, 0.0, 0.5),
+                                                           (4.0, 0.95, 0.3, 0.5), (6.0, 1.0, 0.5, 0.3)])
+def test_search_by_projection_points_rig_matches_oracle(oracle, th, nnratio, random_share, obs_p):
+    """Two-camera frame (F.Nleft != -1): matches propagate to stereo partners, which can re-open a
+    closed keypoint; a failed ratio test on the left skips the right camera."""
+    ka, da, cams, bounds = rig_frames()
+    (exl, kl, dl, csl, el), (exr, kr, dr, csr, er) = cams
+    rng = np.random.default_rng(21)
+    l2r, r2l = stereo_partners(kl, kr, 15.0, rng, random_share)
+    assert (l2r >= 0).sum() > 100
+    # every last-frame keypoint twice, as two map points with slightly different projections
+    rep = np.concatenate([np.arange(len(ka)), np.arange(len(ka))])
+    rng.shuffle(rep)
+    n_pts = len(rep)
+    jit = 1.5
+    proj = np.stack([ka["x"][rep] + 6 + rng.uniform(-jit, jit, n_pts), ka["y"][rep] + rng.uniform(-jit, jit, n_pts)],
+                    1).astype(np.float32)
+    proj_r = np.stack([ka["x"][rep] - 9 + rng.uniform(-jit, jit, n_pts), ka["y"][rep] + rng.uniform(-jit, jit, n_pts)],
+                      1).astype(np.float32)
+    level = ka["octave"][rep].astype(np.int32)
+    level_r = np.where(rng.random(n_pts) < 0.1, -1, np.clip(level + rng.integers(-1, 2, n_pts), 0, 7)).astype(np.int32)
+    view = (rng.random(n_pts) < 0.85).astype(np.uint8)
+    view_r = (rng.random(n_pts) < 0.85).astype(np.uint8)
+    cos = rng.choice([0.9, 0.9985, 0.9999], n_pts).astype(np.float32)
+    cos_r = rng.choice([0.9, 0.9985, 0.9999], n_pts).astype(np.float32)
+    desc = da[rep].copy()
+    desc[:, 3] ^= rng.integers(0, 8, n_pts).astype(np.uint8)
+    obs = (rng.random(n_pts) < obs_p).astype(np.uint8)
+    sl = rng.choice([0, 0, 0, 1, 2], len(kl)).astype(np.uint8)
+    sr = rng.choice([0, 0, 0, 1, 2], len(kr)).astype(np.uint8)
+    sf = np.array(exl.GetScaleFactors(), np.float32)
+    want_n, want_l, want_r = oracle.search_by_projection_points_rig(
+        view, proj, level, cos, view_r, proj_r, level_r, cos_r, desc, obs, (kl, dl, sl, csl, el),
+        (kr, dr, sr, csr, er), l2r, r2l, bounds, sf, th, nnratio)
+    n, al, ar, rounds = guided.search_by_projection_points_rig(exl, exr, 0, view, proj, level, cos, view_r, proj_r,
+                                                               level_r, cos_r, desc, obs, l2r, r2l, sl, sr, th, nnratio)
+    assert n == want_n and np.array_equal(al, want_l) and np.array_equal(ar, want_r), (th, nnratio, random_share)
+    assert 1 <= rounds <= 40, rounds
+    assert (al >= 0).sum() > 100 and (ar >= 0).sum() > 100
+    # one camera's view only, and no partners at all
+    none_l, none_r = -np.ones(len(kl), np.int32), -np.ones(len(kr), np.int32)
+    for v, vr in ((view, view_r * 0), (view * 0, view_r)):
+        want_n, want_l, want_r = oracle.search_by_projection_points_rig(
+            v, proj, level, cos, vr, proj_r, level_r, cos_r, desc, obs, (kl, dl, sl * 0, csl, el),
+            (kr, dr, sr * 0, csr, er), none_l, none_r, bounds, sf, th, nnratio)
+        n, al, ar, rounds = guided.search_by_projection_points_rig(exl, exr, 0, v, proj, level, cos, vr, proj_r,
+                                                                   level_r, cos_r, desc, obs, none_l, none_r, None,
+                                                                   None, th, nnratio)
+        assert n == want_n and np.array_equal(al, want_l) and np.array_equal(ar, want_r)
+
+
 def test_search_by_projection_empty_inputs(oracle):
     exb, ka, da, kb, db, bounds, cs, ent = two_frames(376, 240, params=(300, 1.2, 4, 20, 7))
     n, asg, rounds = guided.search_by_projection_last(exb, 0, np.zeros(0, np.uint8), np.zeros((0, 2), np.float32),
@@ -149,6 +280,40 @@ def test_guided_argument_errors():
         guided.search_by_projection_last(ex, 0, np.ones(1, np.uint8), np.zeros((1, 2)), np.ones(1),
                                          np.array([9]), np.zeros(1), np.zeros((1, 32)), np.ones(1))
     assert e.value.status == ORBX_ERR_BAD_ARG
+
+
+def test_rig_argument_errors():
+    from orb_slam3_amd._lib import OrbxError, ORBX_ERR_BAD_ARG
+    ka, da, cams, bounds = rig_frames(376, 240, params=(300, 1.2, 4, 20, 7))
+    (exl, kl, dl, csl, el), (exr, kr, dr, csr, er) = cams
+    m = len(ka)
+    last = (np.ones(m, np.uint8), np.zeros((m, 2), np.float32), np.ones(m, np.float32), np.zeros((m, 2), np.float32),
+            ka["octave"], ka["angle"], da, np.ones(m, np.uint8))
+    with pytest.raises(OrbxError) as e:      # one handle for both cameras
+        guided.search_by_projection_last_rig(exl, exl, 0, *last)
+    assert e.value.status == ORBX_ERR_BAD_ARG
+    other = orbx.ORBextractor(300, 1.2, 4, 20, 7)
+    other(orbx.textured_frame(3, 376, 240), None, (0, 0))
+    grid.frame_grid_batch(other, 1, None, grid.image_bounds(None, 376, 200))
+    with pytest.raises(OrbxError) as e:      # the two cameras' grids disagree on the image bounds
+        guided.search_by_projection_last_rig(exl, other, 0, *last)
+    assert e.value.status == ORBX_ERR_BAD_ARG
+    pts = (np.ones(m, np.uint8), np.zeros((m, 2)), ka["octave"], np.ones(m), np.ones(m, np.uint8), np.zeros((m, 2)),
+           ka["octave"], np.ones(m), da, np.ones(m, np.uint8))
+    l2r, r2l = -np.ones(len(kl), np.int32), -np.ones(len(kr), np.int32)
+    l2r[0] = len(kr)                         # partner index outside the right camera
+    with pytest.raises(OrbxError) as e:
+        guided.search_by_projection_points_rig(exl, exr, 0, *pts, l2r, r2l)
+    assert e.value.status == ORBX_ERR_BAD_ARG
+    l2r[0] = -1
+    lvl_r = ka["octave"].copy()
+    lvl_r[0] = 9                             # right level outside the pyramid (-1 alone means none)
+    with pytest.raises(OrbxError) as e:
+        guided.search_by_projection_points_rig(exl, exr, 0, *pts[:6], lvl_r, *pts[7:], l2r, r2l)
+    assert e.value.status == ORBX_ERR_BAD_ARG
+    lvl_r[0] = -1
+    n, al, ar, _ = guided.search_by_projection_points_rig(exl, exr, 0, *pts[:6], lvl_r, *pts[7:], l2r, r2l)
+    assert n >= 0 and len(al) == len(kl) and len(ar) == len(kr)
 
 
 def test_results_derived_from_an_extraction_expire_with_it():
