@@ -497,6 +497,15 @@ int orbx_extractor::buildPlan(int W, int H) {
   hp.max_batch = B;
   for (int i = 0; i < 16; ++i) hp.umax[i] = umax[i];
   for (int i = 0; i < 16; ++i) hp.umax_packed |= (unsigned long long)(umax[i] & 15) << (4 * i);
+  for (int j = 0; j < 32; ++j)
+    for (int w = 0; w < 8; ++w) {
+      uint32_t m = 0;
+      for (int k = 0; k < 4; ++k) {
+        const int u = 4 * w + k - 15, av = j < 31 ? std::abs(j - 15) : 16;
+        if (av < 16 && std::abs(u) <= umax[av]) m |= 0xFFu << (8 * k);
+      }
+      hp.ic_mask[j][w] = m;
+    }
 
   size_t pyrOff = 0, blurOff = 0;
   uint32_t candOff = 0, flatOff = 0;

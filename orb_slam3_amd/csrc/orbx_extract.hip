@@ -375,23 +375,18 @@ __device__ __forceinline__ int fast_m(const uint8_t* c) {
   d[13] = v - c[1 * TS - 3];
   d[14] = v - c[2 * TS - 2];
   d[15] = v - c[3 * TS - 1];
-  int lo2[16], hi2[16], lo4[16], hi4[16];
+  // minimum / maximum of every 3 consecutive differences, then of every 9 (three such windows)
+  int lo3[16], hi3[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
-    lo2[k] = min(d[k], d[(k + 1) & 15]);
-    hi2[k] = max(d[k], d[(k + 1) & 15]);
-  }
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    lo4[k] = min(lo2[k], lo2[(k + 2) & 15]);
-    hi4[k] = max(hi2[k], hi2[(k + 2) & 15]);
+    lo3[k] = min(min(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
+    hi3[k] = max(max(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
   }
   int best_dark = -256, best_bright = 256;
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
-    // window of 9 starting at k: [k,k+4) u [k+4,k+8) u {k+8}
-    const int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);
-    const int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);
+    const int lo9 = min(min(lo3[k], lo3[(k + 3) & 15]), lo3[(k + 6) & 15]);
+    const int hi9 = max(max(hi3[k], hi3[(k + 3) & 15]), hi3[(k + 6) & 15]);
     best_dark = max(best_dark, lo9);
     best_bright = min(best_bright, hi9);
   }
@@ -426,15 +421,17 @@ __device__ __forceinline__ int fast_m_sel(const uint8_t* c, int s8) {
   const int v = (int)c[0] ^ s8;
 #pragma unroll
   for (int k = 0; k < 16; ++k) d[k] ^= s8;
-  int lo2[16], lo4[16];
+  // three-input min / max (v_min3 / v_max3 cost what the two-input forms cost): the minimum of
+  // every 3 consecutive ring pixels, then of every 9 = three such windows, then the largest of
+  // the sixteen: 16 + 16 + 8 instructions
+  int lo3[16], lo9[16];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) lo2[k] = min(d[k], d[(k + 1) & 15]);
+  for (int k = 0; k < 16; ++k) lo3[k] = min(min(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
 #pragma unroll
-  for (int k = 0; k < 16; ++k) lo4[k] = min(lo2[k], lo2[(k + 2) & 15]);
+  for (int k = 0; k < 16; ++k) lo9[k] = min(min(lo3[k], lo3[(k + 3) & 15]), lo3[(k + 6) & 15]);
   int best = 0;
 #pragma unroll
-  for (int k = 0; k < 16; ++k)   // window of 9 starting at k: [k,k+4) u [k+4,k+8) u {k+8}
-    best = max(best, min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]));
+  for (int k = 0; k < 16; k += 2) best = max(max(lo9[k], lo9[k + 1]), best);
   return max(best - v, 0);
 }
 
@@ -1639,6 +1636,11 @@ __constant__ __attribute__((aligned(16))) int8_t c_pattern[256 * 4] = {
 #include "orb_pattern_31.inc"
 };
 
+// the same coordinates as floats, for the kernel that rotates them (no conversions in its loop)
+__constant__ __attribute__((aligned(16))) float c_pattern_f[256 * 4] = {
+#include "orb_pattern_31.inc"
+};
+
 // cv::fastAtan2 (degrees).
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
   const float k = (float)(180.0 / 3.1415926535897932384626433832795);
@@ -1886,18 +1888,20 @@ __global__ __launch_bounds__(64) void k_orient_describe(const Plan* __restrict__
 #define FW_CHUNKS (FW_ROWS * 3)               // 16-byte chunks of the raw window
 #define FW_STAGE 5                            // chunks per lane (32 lanes per keypoint)
 
-// the 4 horizontal sums of one window row from its dwords g, g+1, g+2 (LDS)
+// the 4 horizontal sums of one window row from its dwords g, g+1, g+2 (LDS): column c sums window
+// bytes c .. c + 6 with the weights {18,34,48,56,48,34,18}; instead of re-basing the bytes for
+// every column the weights are laid where the bytes are (zero elsewhere): 10 byte dot products
 __device__ __forceinline__ void blur_hrow_lds(const uint32_t* rp, uint32_t (&h)[4]) {
   const uint32_t d0 = rp[0], d1 = rp[1], d2 = rp[2];
-  const uint32_t KLO = 18u | (34u << 8) | (48u << 16) | (56u << 24);
-  const uint32_t KHI = 48u | (34u << 8) | (18u << 16);
-  h[0] = __builtin_amdgcn_udot4(d0, KLO, __builtin_amdgcn_udot4(d1, KHI, 0u, false), false);
-#pragma unroll
-  for (int c = 1; c < 4; ++c) {
-    const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, c);
-    const uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, c);
-    h[c] = __builtin_amdgcn_udot4(lo, KLO, __builtin_amdgcn_udot4(hi, KHI, 0u, false), false);
-  }
+  const uint32_t w0 = 18u, w1 = 34u, w2 = 48u, w3 = 56u;
+  const uint32_t K0a = w0 | (w1 << 8) | (w2 << 16) | (w3 << 24), K0b = w2 | (w1 << 8) | (w0 << 16);
+  const uint32_t K1a = (w0 << 8) | (w1 << 16) | (w2 << 24), K1b = w3 | (w2 << 8) | (w1 << 16) | (w0 << 24);
+  const uint32_t K2a = (w0 << 16) | (w1 << 24), K2b = w2 | (w3 << 8) | (w2 << 16) | (w1 << 24), K2c = w0;
+  const uint32_t K3a = w0 << 24, K3b = w1 | (w2 << 8) | (w3 << 16) | (w2 << 24), K3c = w1 | (w0 << 8);
+  h[0] = __builtin_amdgcn_udot4(d0, K0a, __builtin_amdgcn_udot4(d1, K0b, 0u, false), false);
+  h[1] = __builtin_amdgcn_udot4(d0, K1a, __builtin_amdgcn_udot4(d1, K1b, 0u, false), false);
+  h[2] = __builtin_amdgcn_udot4(d0, K2a, __builtin_amdgcn_udot4(d1, K2b, __builtin_amdgcn_udot4(d2, K2c, 0u, false), false), false);
+  h[3] = __builtin_amdgcn_udot4(d0, K3a, __builtin_amdgcn_udot4(d1, K3b, __builtin_amdgcn_udot4(d2, K3c, 0u, false), false), false);
 }
 
 __global__ __launch_bounds__(64) void k_orient_blur_describe(const Plan* __restrict__ plan,
@@ -1956,11 +1960,10 @@ __global__ __launch_bounds__(64) void k_orient_blur_describe(const Plan* __restr
   int m10, m01;
   {
     const int s0 = off + 6, dw0 = s0 >> 2, sh = s0 & 3;
-    const unsigned long long umaxPacked = plan->umax_packed;
     const int v = j32 - 15;
-    const int av = v < 0 ? -v : v;
-    const int lim = av < 16 ? (int)((umaxPacked >> (4 * av)) & 15u) : -1;
-    const uint32_t lo4 = (uint32_t)(15 - lim) * 0x01010101u, hi4 = ((uint32_t)(15 + lim) * 0x01010101u) | 0x80808080u;
+    // byte masks of the lane's patch row (|u| <= umax[|v|]; all zero for lane 31, which has no row)
+    const uint4 mka = *(const uint4*)&plan->ic_mask[j32][0], mkb = *(const uint4*)&plan->ic_mask[j32][4];
+    const uint32_t mk[8] = {mka.x, mka.y, mka.z, mka.w, mkb.x, mkb.y, mkb.z, mkb.w};
     const uint32_t* rp = raw + min(j32 + 6, FW_ROWS - 1) * WIN_ROW_DW + dw0;
     uint32_t d[9];
 #pragma unroll
@@ -1968,10 +1971,7 @@ __global__ __launch_bounds__(64) void k_orient_blur_describe(const Plan* __restr
     uint32_t sI = 0, sW = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const uint32_t ci = 0x03020100u + 0x04040404u * (uint32_t)i;
-      const uint32_t ok = ((ci | 0x80808080u) - lo4) & (hi4 - ci) & 0x80808080u;
-      const uint32_t mk = lim < 0 ? 0u : (ok << 1) - (ok >> 7);
-      const uint32_t x = __builtin_amdgcn_alignbyte(d[i + 1], d[i], sh) & mk;
+      const uint32_t x = __builtin_amdgcn_alignbyte(d[i + 1], d[i], sh) & mk[i];
       const uint32_t wk = (uint32_t)(4 * i + 1) | ((uint32_t)(4 * i + 2) << 8) | ((uint32_t)(4 * i + 3) << 16) |
                           ((uint32_t)(4 * i + 4) << 24);
       sI = __builtin_amdgcn_udot4(x, 0x01010101u, sI, false);
@@ -2059,28 +2059,28 @@ __global__ __launch_bounds__(64) void k_orient_blur_describe(const Plan* __restr
   // ---- steered BRIEF on the blurred window (extractor.cc:102-145) ---------------------
   // blurred window (row, column) = level (cy - 18 + row, cx - 18 - off + column); lane j
   // evaluates tests 8 j .. 8 j + 7 = descriptor byte j
+  // cvRound of a rotated coordinate (round half to even): adding 1.5 * 2^23 rounds the sum to an
+  // integer the same way and leaves that integer in the low mantissa bits, 0x400000 + n in the low
+  // 24, so row * 40 + column comes out of one 24-bit multiply-add on the raw bits; what the
+  // biases add up to is taken off the base address once
+  const float RND = 12582912.0f;
+  const uint32_t RND_BITS = 0x4B400000u;
+  const uint32_t BIAS = 0x400000u * (uint32_t)(4 * FW_B_ROW_DW) + RND_BITS;
   const uint8_t* bc = (const uint8_t*)blw + 18 * (4 * FW_B_ROW_DW) + (off + 18);
-  const uint4* pp = (const uint4*)(c_pattern + 32 * j32);
+  const float4* pp = (const float4*)(c_pattern_f + 32 * j32);
   uint32_t bits = 0;
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const uint4 w4 = pp[q];
-    const uint32_t ws[4] = {w4.x, w4.y, w4.z, w4.w};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const uint32_t w = ws[e];   // x0, y0, x1, y1 of test 8 j + 4 q + e
-      const float x0 = (float)(int8_t)(w & 0xFF), y0 = (float)(int8_t)((w >> 8) & 0xFF);
-      const float x1 = (float)(int8_t)((w >> 16) & 0xFF), y1 = (float)(int8_t)(w >> 24);
-      // cvRound of the rotated coordinates (round half to even), then row * 40 + column; both are
-      // small integers held in floats, so the fused multiply-add is exact
-      const float r0 = rintf(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
-      const float q0 = rintf(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
-      const float r1 = rintf(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
-      const float q1 = rintf(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-      const int t0 = bc[(int)__fmaf_rn(r0, (float)(4 * FW_B_ROW_DW), q0)];
-      const int t1 = bc[(int)__fmaf_rn(r1, (float)(4 * FW_B_ROW_DW), q1)];
-      bits |= (t0 < t1 ? 1u : 0u) << (q * 4 + e);
-    }
+  for (int e = 0; e < 8; ++e) {
+    const float4 w = pp[e];   // x0, y0, x1, y1 of test 8 j + e
+    const float r0 = __fadd_rn(__fadd_rn(__fmul_rn(w.x, b), __fmul_rn(w.y, a)), RND);
+    const float q0 = __fadd_rn(__fsub_rn(__fmul_rn(w.x, a), __fmul_rn(w.y, b)), RND);
+    const float r1 = __fadd_rn(__fadd_rn(__fmul_rn(w.z, b), __fmul_rn(w.w, a)), RND);
+    const float q1 = __fadd_rn(__fsub_rn(__fmul_rn(w.z, a), __fmul_rn(w.w, b)), RND);
+    const uint32_t i0 = __umul24(__float_as_uint(r0), (uint32_t)(4 * FW_B_ROW_DW)) + __float_as_uint(q0) - BIAS;
+    const uint32_t i1 = __umul24(__float_as_uint(r1), (uint32_t)(4 * FW_B_ROW_DW)) + __float_as_uint(q1) - BIAS;
+    const int t0 = bc[(int)i0];
+    const int t1 = bc[(int)i1];
+    bits |= (t0 < t1 ? 1u : 0u) << e;
   }
   if (valid) {
     const size_t slot = (size_t)f * plan->kp_cap + wi.dst;

@@ -113,6 +113,9 @@ struct Plan {
   uint32_t oct_ws_bytes; // 0: node arrays in LDS; else bytes of global workspace per (frame, level)
   int umax[16];          // circular patch row half-widths (extractor.cc:448-462)
   unsigned long long umax_packed;   // umax[v] in bits 4 v .. 4 v + 3
+  // per patch row v = j - 15 (j = 0 .. 30; row 31 empty): 0xff in byte b of the row's 32 bytes
+  // where pixel u = b - 15 lies inside the circular patch, |u| <= umax[|v|] (extractor.cc:75-99)
+  uint32_t ic_mask[32][8];
   LevelDesc lv[ORBX_MAX_LEVELS];
 };
 
