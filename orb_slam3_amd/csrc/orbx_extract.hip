@@ -2070,7 +2070,7 @@ __global__ __launch_bounds__(64) void k_orient_blur_describe(const Plan* __restr
   const float4* pp = (const float4*)(c_pattern_f + 32 * j32);
   uint32_t bits = 0;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
+  for (int e = 7; e >= 0; --e) {   // highest bit first: each test shifts the earlier ones up
     const float4 w = pp[e];   // x0, y0, x1, y1 of test 8 j + e
     const float r0 = __fadd_rn(__fadd_rn(__fmul_rn(w.x, b), __fmul_rn(w.y, a)), RND);
     const float q0 = __fadd_rn(__fsub_rn(__fmul_rn(w.x, a), __fmul_rn(w.y, b)), RND);
@@ -2080,7 +2080,8 @@ __global__ __launch_bounds__(64) void k_orient_blur_describe(const Plan* __restr
     const uint32_t i1 = __umul24(__float_as_uint(r1), (uint32_t)(4 * FW_B_ROW_DW)) + __float_as_uint(q1) - BIAS;
     const int t0 = bc[(int)i0];
     const int t1 = bc[(int)i1];
-    bits |= (t0 < t1 ? 1u : 0u) << e;
+    // bits = bits << 1 | (t0 < t1): the sign of t0 - t1 moves in from below
+    bits = __builtin_amdgcn_alignbit(bits, (uint32_t)(t0 - t1), 31);
   }
   if (valid) {
     const size_t slot = (size_t)f * plan->kp_cap + wi.dst;

@@ -407,6 +407,9 @@ static inline int __mul24(int a, int b) {
   const int a24 = (int)((uint32_t)a << 8) >> 8, b24 = (int)((uint32_t)b << 8) >> 8;   // sign-extended low 24 bits
   return (int)((uint32_t)a24 * (uint32_t)b24);
 }
+static inline uint32_t __builtin_amdgcn_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) {
+  return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (sh & 31));
+}
 static inline uint32_t __umul24(uint32_t a, uint32_t b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
 static inline int __popc(uint32_t v) { return __builtin_popcount(v); }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
