@@ -623,6 +623,160 @@ def rounds_search_by_projection_points(in_view, proj, proj_xr, level, view_cos, 
     return nm, assigned, rounds
 
 
+def search_by_projection_last_rig(last_valid, uv_l, invz, uv_r, last_octave, last_angle, last_desc, last_obs, cam_l,
+                                  cam_r, bounds, scale, th, forward, backward, check_orientation):
+    """ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) for a current frame with two
+    cameras (matcher.cc:1591-1808, Nleft != -1).  cam = (keypoints, descriptors, state, grid)."""
+    (kl, dl, sl, gl), (kr, dr, sr, gr) = cam_l, cam_r
+    asg = [[-1] * len(kl), [-1] * len(kr)]
+    blocked = [[x == 1 for x in sl], [x == 1 for x in sr]]
+    hist = [[] for _ in range(HISTO_LENGTH)]
+    nm = 0
+    for i in range(len(last_valid)):
+        if not last_valid[i] or F32(invz[i]) < 0:
+            continue
+        u, v = F32(uv_l[i][0]), F32(uv_l[i][1])
+        if u < bounds[0] or u > bounds[1] or v < bounds[2] or v > bounds[3]:
+            continue
+        o = int(last_octave[i])
+        radius = F32(th) * scale[o]
+        lo, hi = (o, -1) if forward else ((0, o) if backward else (o - 1, o + 1))
+        cand = features_in_area(kl, gl, bounds, u, v, radius, lo, hi)
+        if not cand:
+            continue                     # :1652 leaves the loop body: no right camera either
+        for cam, (k, d, c) in enumerate(((kl, dl, cand), (kr, dr, None))):
+            if cam == 1:                 # :1712-1786; the right projection is not checked against the image
+                c = features_in_area(kr, gr, bounds, F32(uv_r[i][0]), F32(uv_r[i][1]), radius, lo, hi)
+            best, bi = 256, -1
+            for i2 in c:
+                if blocked[cam][i2]:
+                    continue
+                dist = hamming(last_desc[i], d[i2])
+                if dist < best:
+                    best, bi = dist, i2
+            if bi >= 0 and best <= 100:
+                asg[cam][bi] = i
+                blocked[cam][bi] = bool(last_obs[i])
+                nm += 1
+                if check_orientation:
+                    hist[rotation_bin(last_angle[i], k["angle"][bi])].append((cam, bi))
+    if check_orientation:
+        keep = three_maxima([len(h) for h in hist])
+        for b in range(HISTO_LENGTH):
+            if b in keep:
+                continue
+            for cam, i2 in hist[b]:
+                asg[cam][i2] = -2
+                nm -= 1
+    return nm, asg[0], asg[1]
+
+
+def _point_choice3(lst, is_blocked, nnratio):
+    """_point_choice with the two ways of failing told apart: -1 nothing within TH_HIGH, -2 the
+    ratio test failed (matcher.cc:123-124 leaves the map point's loop body)."""
+    best = best2 = 256
+    lvl = lvl2 = bi = -1
+    for i2, dist, octave in lst:
+        if is_blocked(i2):
+            continue
+        if dist < best:
+            best2, best, lvl2, lvl, bi = best, dist, lvl, octave, i2
+        elif dist < best2:
+            lvl2, best2 = octave, dist
+    if best > 100:
+        return -1
+    if lvl == lvl2 and F32(best) > F32(nnratio) * F32(best2):
+        return -2
+    return bi
+
+
+def _rig_candidates(pts, cam_l, cam_r, bounds, scale, th):
+    in_view, proj, level, view_cos, in_view_r, proj_r, level_r, view_cos_r, pt_desc = pts
+    (kl, dl, _, gl), (kr, dr, _, gr) = cam_l, cam_r
+    zero = np.zeros(len(in_view), np.float32)
+    cl = _point_candidates(in_view, proj, zero, level, view_cos, pt_desc, kl, dl, None, gl, bounds, scale, th)
+    view_r = [bool(in_view_r[i]) and int(level_r[i]) != -1 for i in range(len(in_view))]     # :144-146
+    cr = _point_candidates(view_r, proj_r, zero, np.maximum(level_r, 0), view_cos_r, pt_desc, kr, dr, None, gr,
+                           bounds, scale, 1.0)                                               # :147: no th
+    return cl, cr
+
+
+def search_by_projection_points_rig(pts, pt_obs, cam_l, cam_r, l2r, r2l, bounds, scale, th, nnratio):
+    """ORBmatcher::SearchByProjection(F, vpMapPoints, th, ...) for a frame with two cameras
+    (matcher.cc:41-213).  pts = (in_view, proj, level, view_cos, in_view_r, proj_r, level_r,
+    view_cos_r, desc); cam = (keypoints, descriptors, state, grid)."""
+    cl, cr = _rig_candidates(pts, cam_l, cam_r, bounds, scale, th)
+    asg = [[-1] * len(cam_l[0]), [-1] * len(cam_r[0])]
+    blocked = [[x == 1 for x in cam_l[2]], [x == 1 for x in cam_r[2]]]
+    partner = [l2r, r2l]
+    nm = 0
+    for i in range(len(pt_obs)):
+        for cam, lst in ((0, cl[i]), (1, cr[i])):
+            c = _point_choice3(lst, lambda i2: blocked[cam][i2], nnratio)
+            if c == -2 and cam == 0:
+                break
+            if c >= 0:
+                asg[cam][c] = i
+                blocked[cam][c] = bool(pt_obs[i])
+                nm += 1
+                p = int(partner[cam][c])
+                if p != -1:                                   # :129-135, :197-203: whatever it held
+                    asg[1 - cam][p] = i
+                    blocked[1 - cam][p] = bool(pt_obs[i])
+                    nm += 1
+    return nm, asg[0], asg[1]
+
+
+def rounds_search_by_projection_points_rig(pts, pt_obs, cam_l, cam_r, l2r, r2l, bounds, scale, th, nnratio):
+    """The same result from rounds of independent decisions.  Map point i decides for the left
+    camera at time 2i and for the right one at 2i + 1; a decision writes the point into its
+    keypoint and into the keypoint's partner in the other camera.  A keypoint is closed at time t
+    when the latest write before t carried a point with observations (none yet: its initial
+    state).  Every round decides from the writes of the previous round's decisions; a decision
+    only depends on earlier times, so the rounds settle on the sequential loop's result."""
+    cl, cr = _rig_candidates(pts, cam_l, cam_r, bounds, scale, th)
+    cand = [cl, cr]
+    n_pts = len(pt_obs)
+    sizes = [len(cam_l[0]), len(cam_r[0])]
+    init = [[x == 1 for x in cam_l[2]], [x == 1 for x in cam_r[2]]]
+    partner = [l2r, r2l]
+    choice = [[-1] * n_pts, [-1] * n_pts]
+    rounds = 0
+
+    def writes_of(choice):
+        w = [[[] for _ in range(sizes[0])], [[] for _ in range(sizes[1])]]     # per keypoint: (time, point)
+        for i in range(n_pts):
+            for cam in (0, 1):
+                c = choice[cam][i]
+                if c >= 0:
+                    w[cam][c].append((2 * i + cam, i))
+                    p = int(partner[cam][c])
+                    if p != -1:
+                        w[1 - cam][p].append((2 * i + cam, i))
+        return w
+
+    while True:
+        rounds += 1
+        w = writes_of(choice)
+
+        def closed(cam, i2, t):
+            before = [e for e in w[cam][i2] if e[0] < t]
+            return bool(pt_obs[max(before)[1]]) if before else init[cam][i2]
+
+        new = [[-1] * n_pts, [-1] * n_pts]
+        for i in range(n_pts):
+            c0 = _point_choice3(cand[0][i], lambda i2: closed(0, i2, 2 * i), nnratio)
+            new[0][i] = c0
+            new[1][i] = -1 if c0 == -2 else _point_choice3(cand[1][i], lambda i2: closed(1, i2, 2 * i + 1), nnratio)
+        if new == choice:
+            break
+        choice = new
+    w = writes_of(choice)
+    asg = [[max(e)[1] if e else -1 for e in w[cam]] for cam in (0, 1)]
+    nm = sum(len(e) for cam in (0, 1) for e in w[cam])
+    return nm, asg[0], asg[1], rounds
+
+
 def search_by_bow(kf_valid, kf_angle, kf_desc, kf_fv, f_angle, f_desc, f_fv, nnratio, check_orientation):
     """ORBmatcher::SearchByBoW(pKF, F, ...), matcher.cc:222-405, Nleft == -1.  kf_fv / f_fv: dicts
     node id -> list of feature indices (the FeatureVector maps)."""

@@ -245,6 +245,103 @@ def test_search_by_projection_points(oracle):
     assert worst <= 10, worst
 
 
+def _rig_cameras(oracle):
+    """A last frame and the two cameras of the current one: shifted views of one texture."""
+    import orb_slam3_amd as orbx
+    params = (400, 1.2, 4, 20, 7)
+    pad, w, h = 16, 320, 240
+    wide = orbx.textured_frame(47, w + 2 * pad, h)
+    ea = oracle.Extractor(*params)
+    _, _, ka, da = ea.extract(np.ascontiguousarray(wide[:, pad:pad + w]), (0, 0))
+    bounds = oracle.image_bounds(None, w, h)
+    cams = []
+    for sh in (6, -9):
+        e = oracle.Extractor(*params)
+        _, _, k, d = e.extract(np.ascontiguousarray(wide[:, pad - sh:pad - sh + w]), (0, 0))
+        un, cs, ent = oracle.frame_grid(None, bounds, k)
+        cams.append((un, d, cs, ent))
+    return params, ka, da, cams, bounds
+
+
+def test_search_by_projection_last_rig(oracle):
+    params, ka, da, cams, bounds = _rig_cameras(oracle)
+    (kl, dl, csl, el), (kr, dr, csr, er) = cams
+    rng = np.random.default_rng(12)
+    scale, _ = S.level_tables(params[2], params[1])
+    n = len(ka)
+    uvl = np.stack([ka["x"] + 6 + rng.uniform(-2, 2, n), ka["y"] + rng.uniform(-2, 2, n)], 1).astype(np.float32)
+    uvr = np.stack([ka["x"] - 9 + rng.uniform(-2, 2, n), ka["y"] + rng.uniform(-2, 2, n)], 1).astype(np.float32)
+    uvl[::17] += 500
+    uvr[::13] -= 400
+    invz = rng.uniform(0.05, 1.0, n).astype(np.float32)
+    invz[::23] = -0.1
+    valid = (rng.random(n) < 0.9).astype(np.uint8)
+    obs = (rng.random(n) < 0.7).astype(np.uint8)
+    sl = rng.choice([0, 0, 0, 1, 2], len(kl)).astype(np.uint8)
+    sr = rng.choice([0, 0, 0, 1, 2], len(kr)).astype(np.uint8)
+    gl, gr = S.frame_grid(kl, bounds), S.frame_grid(kr, bounds)
+    for forward, backward, th, ori in [(0, 0, 15.0, True), (1, 0, 15.0, True), (0, 1, 7.0, False), (0, 0, 30.0, True)]:
+        want = oracle.search_by_projection_last_rig(valid, uvl, invz, uvr, ka["octave"], ka["angle"], da, obs,
+                                                    (kl, dl, sl, csl, el), (kr, dr, sr, csr, er), bounds,
+                                                    np.array(scale, np.float32), th, forward, backward, ori)
+        got = S.search_by_projection_last_rig(valid, uvl, invz, uvr, ka["octave"], ka["angle"], da, obs,
+                                              (kl, dl, sl, gl), (kr, dr, sr, gr), bounds, scale, th, forward,
+                                              backward, ori)
+        assert (want[0], want[1].tolist(), want[2].tolist()) == got, (forward, backward, th)
+        assert (want[1] >= 0).sum() > 20 and (want[2] >= 0).sum() > 20
+
+
+def test_search_by_projection_points_rig(oracle):
+    """Sequential oracle == sequential numpy == rounds form with per-keypoint write lists, with
+    mutual partner links and with arbitrary one-way ones (which re-open closed keypoints)."""
+    params, ka, da, cams, bounds = _rig_cameras(oracle)
+    (kl, dl, csl, el), (kr, dr, csr, er) = cams
+    rng = np.random.default_rng(13)
+    scale, _ = S.level_tables(params[2], params[1])
+    gl, gr = S.frame_grid(kl, bounds), S.frame_grid(kr, bounds)
+    rep = np.concatenate([np.arange(len(ka)), np.arange(len(ka))])
+    rng.shuffle(rep)
+    n = len(rep)
+    proj = np.stack([ka["x"][rep] + 6 + rng.uniform(-1.5, 1.5, n), ka["y"][rep] + rng.uniform(-1.5, 1.5, n)], 1).astype(np.float32)
+    proj_r = np.stack([ka["x"][rep] - 9 + rng.uniform(-1.5, 1.5, n), ka["y"][rep] + rng.uniform(-1.5, 1.5, n)], 1).astype(np.float32)
+    level = ka["octave"][rep].astype(np.int32)
+    level_r = np.where(rng.random(n) < 0.1, -1, np.clip(level + rng.integers(-1, 2, n), 0, params[2] - 1)).astype(np.int32)
+    view = (rng.random(n) < 0.85).astype(np.uint8)
+    view_r = (rng.random(n) < 0.85).astype(np.uint8)
+    cos = rng.choice([0.9, 0.9985, 0.9999], n).astype(np.float32)
+    cos_r = rng.choice([0.9, 0.9985, 0.9999], n).astype(np.float32)
+    desc = da[rep].copy()
+    desc[:, 3] ^= rng.integers(0, 8, n).astype(np.uint8)
+    sl = rng.choice([0, 0, 0, 1, 2], len(kl)).astype(np.uint8)
+    sr = rng.choice([0, 0, 0, 1, 2], len(kr)).astype(np.uint8)
+    worst = 0
+    for th, ratio, share, obs_p in [(1.0, 0.8, 0.0, 0.7), (4.0, 0.95, 0.3, 0.5), (6.0, 1.0, 0.5, 0.3)]:
+        obs = (rng.random(n) < obs_p).astype(np.uint8)
+        l2r, r2l = -np.ones(len(kl), np.int32), -np.ones(len(kr), np.int32)
+        for i in range(len(kl)):          # mutual links: 15 px apart on the same row and level
+            dd = np.abs(kr["x"] - (kl["x"][i] - 15)) + np.abs(kr["y"] - kl["y"][i]) + 100.0 * (kr["octave"] != kl["octave"][i])
+            j = int(np.argmin(dd))
+            if dd[j] <= 1.5 and r2l[j] < 0:
+                l2r[i], r2l[j] = j, i
+        xl, xr = rng.random(len(kl)) < share, rng.random(len(kr)) < share
+        l2r[xl] = rng.integers(0, len(kr), xl.sum())
+        r2l[xr] = rng.integers(0, len(kl), xr.sum())
+        want = oracle.search_by_projection_points_rig(view, proj, level, cos, view_r, proj_r, level_r, cos_r, desc, obs,
+                                                      (kl, dl, sl, csl, el), (kr, dr, sr, csr, er), l2r, r2l, bounds,
+                                                      np.array(scale, np.float32), th, ratio)
+        want = (want[0], want[1].tolist(), want[2].tolist())
+        pts = (view, proj, level, cos, view_r, proj_r, level_r, cos_r, desc)
+        got = S.search_by_projection_points_rig(pts, obs, (kl, dl, sl, gl), (kr, dr, sr, gr), l2r, r2l, bounds, scale,
+                                                th, ratio)
+        assert want == got, (th, ratio, share)
+        rn, ral, rar, rounds = S.rounds_search_by_projection_points_rig(pts, obs, (kl, dl, sl, gl), (kr, dr, sr, gr),
+                                                                        l2r, r2l, bounds, scale, th, ratio)
+        assert want == (rn, ral, rar), (th, ratio, share)
+        worst = max(worst, rounds)
+        assert (np.array(got[1]) >= 0).sum() > 20 and (np.array(got[2]) >= 0).sum() > 20
+    assert worst <= 16, worst
+
+
 def test_search_by_bow(oracle):
     from tests import voc_util
     params, ka, da, kb, db, bounds, cs, ent = _two_frames(oracle)

@@ -227,6 +227,39 @@ def grid_and_matchers(rng, img, params):
                                                             use_ur, use_state, th3, ratio3)
     assert n3m == want_n and np.array_equal(asg3, want), "search by projection of map points"
 
+    # the frame as the left camera of a rig (Nleft != -1): the right camera sees the same content
+    # a few pixels to the side; both matchers in their two-camera forms
+    shift = int(rng.integers(2, 12))
+    right = np.ascontiguousarray(np.roll(img, -shift, axis=1))
+    exr = orbx.ORBextractor(*params)
+    _, kr_raw, drr = exr(right, None, (0, 0))
+    if len(kr_raw) > 0:
+        grid.frame_grid_batch(exr, 1, pc, b)
+        unr, csr, entr = grid.frame_grid_download(exr, 0)
+        state_r = rng.choice([0, 0, 0, 1, 2], len(unr)).astype(np.uint8)
+        st_l = use_state if use_state is not None else np.zeros(len(k), np.uint8)
+        uv_r = (uv - np.array([shift, 0], np.float32) + rng.uniform(-jit, jit, uv.shape)).astype(np.float32)
+        want_n, want_l, want_r = oracle.search_by_projection_last_rig(
+            valid, uv, invz, uv_r, ka["octave"], ka["angle"], da, obs, (un, d, st_l, cs, ent),
+            (unr, drr, state_r, csr, entr), b, sf, th, fwd, bwd, ori)
+        nrig, al, ar, _ = guided.search_by_projection_last_rig(ex, exr, 0, valid, uv, invz, uv_r, ka["octave"],
+                                                               ka["angle"], da, obs, use_state, state_r, th, fwd, bwd,
+                                                               ori)
+        assert nrig == want_n and np.array_equal(al, want_l) and np.array_equal(ar, want_r), "rig search by projection"
+        l2r = np.where(rng.random(len(un)) < 0.4, rng.integers(0, len(unr), len(un)), -1).astype(np.int32)
+        r2l = np.where(rng.random(len(unr)) < 0.4, rng.integers(0, len(un), len(unr)), -1).astype(np.int32)
+        proj_r = (proj - np.array([shift, 0], np.float32) + rng.uniform(-jit, jit, proj.shape)).astype(np.float32)
+        level_r = np.where(rng.random(n3) < 0.1, -1, np.clip(level + rng.integers(-1, 2, n3), 0, params[2] - 1)).astype(np.int32)
+        vcos_r = np.where(rng.random(n3) < 0.5, 0.9995, rng.uniform(0.5, 0.998, n3)).astype(np.float32)
+        in_view_r = (rng.random(n3) < 0.8).astype(np.uint8)
+        want_n, want_l, want_r = oracle.search_by_projection_points_rig(
+            in_view, proj, level, vcos, in_view_r, proj_r, level_r, vcos_r, dp3, obs3, (un, d, st_l, cs, ent),
+            (unr, drr, state_r, csr, entr), l2r, r2l, b, sf, th3, ratio3)
+        nrig3, al, ar, _ = guided.search_by_projection_points_rig(ex, exr, 0, in_view, proj, level, vcos, in_view_r,
+                                                                  proj_r, level_r, vcos_r, dp3, obs3, l2r, r2l,
+                                                                  use_state, state_r, th3, ratio3)
+        assert nrig3 == want_n and np.array_equal(al, want_l) and np.array_equal(ar, want_r), "rig search of map points"
+
     ka0 = ka.copy()
     if rng.random() < 0.7:
         ka0["octave"] = np.where(rng.random(n1) < 0.8, 0, ka0["octave"])

@@ -1,10 +1,12 @@
 #!/bin/bash
-# Runs "knock-out" variants of k_orient_describe (the kind of timing experiment that removes a
+# Runs "knock-out" variants of k_orient_blur_describe (the kind of timing experiment that removes a
 # kernel's loads, its arithmetic or its work-list read to see what bounds it) under the kernel
 # host simulation with guard pages, so that a variant that reads or writes outside its buffers is
 # caught on the CPU and never reaches a GPU.  Nothing here touches the repository's sources: every
-# variant is a patched copy under /tmp.  Usage: tools/knockout_check.sh  (prints one line per variant)
+# variant is a patched copy under /tmp.  Usage: tools/knockout_check.sh  (prints one line per variant;
+# exit status 1 when a patch no longer applies to the sources or a variant does not build)
 set -u
+FAILED=0
 R=$(cd "$(dirname "$0")/.." && pwd)
 CXX=/opt/rocm/lib/llvm/bin/clang++
 SIM=$R/tests/hostsim
@@ -17,7 +19,7 @@ variant() {   # name, python expression list of (old, new) replacements on orbx_
   local name=$1 edits=$2 d=$OUT/$1
   rm -rf "$d" && mkdir -p "$d/src" "$d/_build"
   cp "$R"/orb_slam3_amd/csrc/*.hip "$R"/orb_slam3_amd/csrc/*.h "$R"/orb_slam3_amd/csrc/*.inc "$d/src/"
-  python3 - "$d/src/orbx_extract.hip" "$edits" <<'PY' || { echo "$name: patch did not apply"; return; }
+  python3 - "$d/src/orbx_extract.hip" "$edits" <<'PY' || { echo "$name: patch did not apply"; FAILED=1; return; }
 import sys
 p, edits = sys.argv[1], eval(sys.argv[2])
 s = open(p).read()
@@ -30,7 +32,7 @@ PY
   local objs=""
   for n in $NAMES; do
     sed -E 's/extern __shared__ (__align__\(16\) )?([a-z0-9_]+) ([A-Za-z]+)\[\];/\2* \3 = (\2*)hostsim::dyn_lds();/' "$d/src/$n.hip" > "$d/_build/$n.cpp"
-    $CXX $FLAGS -I"$d/src" -c "$d/_build/$n.cpp" -o "$d/_build/$n.o" || { echo "$name: build failed"; return; }
+    $CXX $FLAGS -I"$d/src" -c "$d/_build/$n.cpp" -o "$d/_build/$n.o" || { echo "$name: build failed"; FAILED=1; return; }
     objs="$objs $d/_build/$n.o"
   done
   $CXX $FLAGS -c "$SIM/hostsim.cpp" -o "$d/_build/hostsim.o"
@@ -61,12 +63,14 @@ PY
 export ORBX_ROOT=$R
 # 0. the committed kernel (control)
 variant control "[]"
-# 1. the staging loads of the un-blurred patch removed (window keeps whatever LDS held)
-variant no_ic_loads "[('      const U4A4 t = *(const U4A4*)(pbase + (size_t)r * ps + 16 * c3);\n      st2[u] = make_uint4(t.x, t.y, t.z, t.w);', '      st2[u] = make_uint4(0, 0, 0, 0); (void)pbase; (void)r; (void)c3;'), ('      if (idx < IC_CHUNKS) *(uint4*)&sWin[slotInBlock][4 * idx] = st2[u];', '      (void)idx;')]"
-# 2. the staging loads of the blurred window removed
-variant no_desc_loads "[('    const U4A4 t = *(const U4A4*)(wbase + (size_t)r * bs + 16 * c3);\n    stage[u] = make_uint4(t.x, t.y, t.z, t.w);', '    stage[u] = make_uint4(0, 0, 0, 0); (void)wbase; (void)r; (void)c3;'), ('    if (idx < DESC_CHUNKS) *(uint4*)&sWin[slotInBlock][4 * idx] = stage[u];', '    (void)idx;')]"
-# 3. the trigonometry removed: the rotation coefficients come from whatever the (uninitialised)
-#    window holds instead of cos / sin of the angle
-variant no_trig "[('  const float a = (float)cos((double)rad), b = (float)sin((double)rad);', '  const float a = __uint_as_float(sWin[slotInBlock][j16]), b = __uint_as_float(sWin[slotInBlock][j16 + 16]); (void)rad;')]"
-# 4. the work-list read removed: every keypoint sits at level 0, position (0, 0)
-variant no_work_item "[('  const WorkItem wi = work[(size_t)f * plan->kp_cap + (valid ? k : n - 1)];', '  WorkItem wi; wi.level = 0; wi.xy = 0; wi.dst = valid ? k : n - 1; wi.pad = 0; (void)work;')]"
+# 1. the staging loads of the keypoint's window removed (the window keeps whatever LDS held)
+variant no_window_loads "[('      const U4A4 t = *(const U4A4*)(pbase + (size_t)r * ps + 16 * c3);\n      st[u] = make_uint4(t.x, t.y, t.z, t.w);', '      st[u] = make_uint4(0, 0, 0, 0); (void)pbase; (void)r; (void)c3;'), ('      if (idx < FW_CHUNKS) *(uint4*)&raw[4 * idx] = st[u];', '      (void)idx;')]"
+# 2. the trigonometry removed: the rotation coefficients come from whatever the window holds
+#    instead of cos / sin of the angle
+variant no_trig "[('  sincos_small((double)rad, sind, cosd);', '  sind = (double)__uint_as_float(raw[j32]); cosd = (double)__uint_as_float(raw[j32 + 32]); (void)rad;')]"
+# 3. the work-list read removed: every keypoint's window starts at byte 0 of the pyramid buffer
+#    with row stride 0 (the record carries the window's address, so nothing leaves the buffer)
+variant no_work_item "[('  const WorkItem wi = work[(size_t)f * plan->kp_cap + (valid ? k : n - 1)];', '  WorkItem wi; wi.level = 0; wi.xy = 0; wi.dst = valid ? k : n - 1; wi.pyr_win = 0; wi.blur_win = 0; wi.strides = 0; (void)work;')]"
+# 4. the blur pass removed: the descriptor samples whatever the blurred window's LDS held
+variant no_blur "[('  if (j32 < 30) {\n    const int band = j32 >= 20 ? 2 : (j32 >= 10 ? 1 : 0);', '  if (false) {\n    const int band = j32 >= 20 ? 2 : (j32 >= 10 ? 1 : 0);')]"
+exit $FAILED
