@@ -854,7 +854,11 @@ int orbx_extractor::run(const uint8_t* d_images, int istride, size_t iframe, int
     // starting one stage behind the previous one, so that the latency-bound pyramid of a part
     // overlaps the VALU-bound detection of the part before it, and its detection overlaps
     // that part's quadtree and descriptors.
-    const int nparts = std::max(1, std::min(maxParts, nframes / kSplitMin));
+    // (a part must be big enough to fill the chip by itself: kSplitMin frames of 752 x 480, fewer
+    // frames of a larger image in proportion)
+    const long long refPixels = (long long)kSplitMin * 752 * 480;
+    const int splitMin = (int)std::max(1LL, std::min((long long)kSplitMin, (refPixels + (long long)hp.W * hp.H - 1) / ((long long)hp.W * hp.H)));
+    const int nparts = std::max(1, std::min(maxParts, nframes / splitMin));
     if (nparts > 1) {
       HIP_TRY(hipEventRecord(evStart, s));            // the other part streams follow earlier work on s
       for (int k = 1; k < nparts; ++k) HIP_TRY(hipStreamWaitEvent(lane[k], evStart, 0));
@@ -1191,6 +1195,62 @@ bool is_pinned_host(const void* p, size_t bytes) {
 }
 }  // namespace
 
+// One frame from host memory, the call Frame::ExtractORB makes (core/src/Frame.cc:461-470): no
+// groups, no helper streams, no packing threads - image in, kernels, counts and results out on the
+// handle's own stream with one synchronisation.  The results travel at full slot capacity beside
+// the counts (one wait instead of count-then-results) unless that is more than a few hundred KB.
+static int extract_one(orbx_extractor* ex, const uint8_t* img, int width, int height, int stride, int lap0,
+                       int lap1, orbx_keypoint* kps, uint8_t* desc, int cap, int* n_out, int* mono_out) {
+  auto& last_hip_error = ex->last_hip_error;
+  hipStream_t s = ex->stream;
+  const size_t frameBytes = (size_t)width * height;
+  const size_t srcBytes = (size_t)stride * (height - 1) + width;
+  const int kc = ex->hp.kp_cap;
+  const int ccap = std::min(cap, kc);
+  const bool wantK = kps && ccap > 0, wantD = desc && ccap > 0;
+  const bool pinnedIn = is_pinned_host(img, srcBytes);
+  int st = ex->ensureHostStaging(!pinnedIn, true);
+  if (st != ORBX_OK) return st;
+  const uint8_t* src = img;
+  int sstride = stride;
+  if (!pinnedIn) {
+    uint8_t* hin = ex->h_in[0];
+    if (stride == width) std::memcpy(hin, img, frameBytes);
+    else for (int y = 0; y < height; ++y) std::memcpy(hin + (size_t)y * width, img + (size_t)y * stride, width);
+    src = hin;
+    sstride = width;
+  }
+  if (sstride == width) HIP_TRY(hipMemcpyAsync(ex->d_img, src, frameBytes, hipMemcpyHostToDevice, s));
+  else HIP_TRY(hipMemcpy2DAsync(ex->d_img, width, src, sstride, width, height, hipMemcpyHostToDevice, s));
+  st = ex->run(ex->d_img, width, frameBytes, 1, lap0, lap1);
+  if (st != ORBX_OK) return st;
+  int* hn = ex->h_cnt[0];
+  uint8_t* hk = ex->h_out[0];
+  uint8_t* hd = hk + (size_t)ex->groupFrames * kc * 28;
+  HIP_TRY(hipMemcpyAsync(hn, ex->d_n, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(hn + 1, ex->d_mono, 4, hipMemcpyDeviceToHost, s));
+  const bool eager = (size_t)ccap * 60 <= (384u << 10);
+  if (eager) {
+    if (wantK) HIP_TRY(hipMemcpyAsync(hk, ex->d_kps, (size_t)ccap * 28, hipMemcpyDeviceToHost, s));
+    if (wantD) HIP_TRY(hipMemcpyAsync(hd, ex->d_desc, (size_t)ccap * 32, hipMemcpyDeviceToHost, s));
+  }
+  HIP_TRY(hipStreamSynchronize(s));
+  const int n = hn[0];
+  if (n_out) *n_out = n;
+  if (mono_out) *mono_out = hn[1];
+  if (n > cap) return ORBX_ERR_CAPACITY;
+  if (n > 0 && !eager) {
+    if (wantK) HIP_TRY(hipMemcpyAsync(hk, ex->d_kps, (size_t)n * 28, hipMemcpyDeviceToHost, s));
+    if (wantD) HIP_TRY(hipMemcpyAsync(hd, ex->d_desc, (size_t)n * 32, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
+  if (n > 0) {
+    if (wantK) std::memcpy(kps, hk, (size_t)n * 28);
+    if (wantD) std::memcpy(desc, hd, (size_t)n * 32);
+  }
+  return ORBX_OK;
+}
+
 int orbx_extract_batch(orbx_extractor* ex, int n_frames, const uint8_t* const* imgs, int width,
                        int height, int stride, int lap0, int lap1, orbx_keypoint* kps,
                        uint8_t* desc, int cap, int* n_out, int* mono_out) {
@@ -1203,6 +1263,7 @@ int orbx_extract_batch(orbx_extractor* ex, int n_frames, const uint8_t* const* i
   if (const int js_ = ex->joinParts()) return js_;
   int st = ex->ensurePlan(width, height);
   if (st != ORBX_OK) { ex->freePlan(); return st; }
+  if (n_frames == 1) return extract_one(ex, imgs[0], width, height, stride, lap0, lap1, kps, desc, cap, n_out, mono_out);
   auto& last_hip_error = ex->last_hip_error;
   const size_t frameBytes = (size_t)width * height;
   const size_t srcBytes = (size_t)stride * (height - 1) + width;

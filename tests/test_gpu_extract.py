@@ -197,14 +197,20 @@ def test_device_resident_batch_matches_host_batch():
         assert mono == host[f][0] and np.array_equal(k, host[f][1]) and np.array_equal(desc, host[f][2])
 
 
-@pytest.mark.parametrize("knob,value", [("ORBX_PYR_XCD", "0"), ("ORBX_PYR_WAVES", "2"), ("ORBX_PYR_WAVES", "4"),
-                                        ("ORBX_BLUR_WAVES", "4"), ("ORBX_SIDE_BLUR", "0"), ("ORBX_SIDE_BLUR", "2"),
-                                        ("ORBX_FAST_SINGLE_PASS", "1"), ("ORBX_OCT_KEYS_LDS", "0")])
-def test_timing_knobs_do_not_change_results(oracle, knob, value, monkeypatch):
+@pytest.mark.parametrize("env", [{"ORBX_PYR_XCD": "0"}, {"ORBX_PYR_WAVES": "2"}, {"ORBX_PYR_WAVES": "4"},
+                                 {"ORBX_BLUR_PLANES": "1"}, {"ORBX_BLUR_PLANES": "1", "ORBX_BLUR_WAVES": "4"},
+                                 {"ORBX_BLUR_PLANES": "1", "ORBX_SIDE_BLUR": "0"},
+                                 {"ORBX_BLUR_PLANES": "1", "ORBX_SIDE_BLUR": "1"},
+                                 {"ORBX_BLUR_PLANES": "1", "ORBX_SIDE_BLUR": "2"},
+                                 {"ORBX_FAST_SINGLE_PASS": "1"}, {"ORBX_OCT_KEYS_LDS": "0"}],
+                         ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
+def test_timing_knobs_do_not_change_results(oracle, env, monkeypatch):
     """The environment knobs that exist for timing experiments (workgroup shapes and numbering, the
-    blur's place in the chain, one detection pass instead of two, quadtree keys outside LDS) select
-    other launch geometries and code paths; every stage must still equal the oracle."""
-    monkeypatch.setenv(knob, value)
+    full-plane blur schedule with its separate descriptor kernel and the blur's place in that
+    chain, one detection pass instead of two, quadtree keys outside LDS) select other launch
+    geometries and code paths; every stage must still equal the oracle."""
+    for knob, value in env.items():
+        monkeypatch.setenv(knob, value)
     compare_full(oracle, orbx.textured_frame(11, 640, 400), (600, 1.2, 6, 20, 7), (0, 1000))
 
 
@@ -244,6 +250,29 @@ def test_split_batch_matches_single_frames():
         mono, k, d = res[f]
         rmono, rk, rd = ref[f % 5]
         assert mono == rmono and np.array_equal(k, rk) and np.array_equal(d, rd), f
+
+
+@pytest.mark.needs_real_device
+def test_large_image_batch_splits_by_work():
+    """A device-resident batch is cut into two parts when each part can fill the chip: 128 frames of
+    752 x 480, fewer of a larger image in proportion (23 at 1920 x 1080).  Frames on both sides of
+    the cut equal their single-frame results."""
+    import torch
+    from tests.conftest import TORCH_DEVICE
+    params = (3000, 1.2, 8, 20, 7)
+    w, h, B = 1920, 1080, 48
+    distinct = [orbx.textured_frame(950 + i, w, h) for i in range(3)]
+    frames = np.stack([distinct[i % 3] for i in range(B)])
+    ex = orbx.ORBextractor(*params, max_batch=B)
+    d = torch.from_numpy(frames).to(TORCH_DEVICE)
+    ex.extract_batch_device(d.data_ptr(), B, w, h, w, (0, 0))
+    assert [fr for _, fr in ex.detect_launch_times()] == [24, 24]     # one detection launch per part
+    single = orbx.ORBextractor(*params)
+    ref = [single(f, None, (0, 0)) for f in distinct]
+    for f in (0, 1, 23, 24, 25, 46, 47):
+        mono, k, desc = ex.download(f)
+        rmono, rk, rd = ref[f % 3]
+        assert mono == rmono and np.array_equal(k, rk) and np.array_equal(desc, rd), f
 
 
 def _pinned_array(shape, dtype):

@@ -30,9 +30,12 @@ def test_gpu_suite_under_host_simulation(guard, order, lib):
     # lib "ubsan": the simulation built with every undefined-behaviour check (signed overflow,
     # shifts, misaligned or null accesses ...) compiled in as a trap
     env = dict(os.environ, ORBX_HOSTSIM="1", HOSTSIM_GUARD=guard, HOSTSIM_ORDER=order, ORBX_HOSTSIM_LIB=lib)
-    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests"), "-m", "gpu", "-q", "-x",
-                          "-p", "no:faulthandler", "-p", "no:cacheprovider"],
-                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    cmd = [sys.executable, "-m", "pytest", os.path.join(ROOT, "tests"), "-m", "gpu", "-q", "-x",
+           "-p", "no:faulthandler", "-p", "no:cacheprovider"]
+    if (guard, order) != ("end", "forward"):
+        # the large-batch schedule cases run in full in the first variant; one of each kind here
+        cmd += ["-k", "not schedule_knobs or PARTS-3 or FAST_QCAP"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     tail = (out.stdout + out.stderr)[-3000:]
     assert out.returncode == 0, tail
     assert " passed" in out.stdout and " failed" not in out.stdout, tail
