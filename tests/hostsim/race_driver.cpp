@@ -151,6 +151,11 @@ int main(int argc, char** argv) {
     CHECK(orbx_lapping_knn2_batch_device(left, right, NF));
     for (int f = 0; f < NF; ++f)
       CHECK(orbx_lapping_knn2_download(left, f, li.data(), ld.data(), cap, &nq, &ml, &nt, &mr));
+    // the ratio test on the records where they lie
+    CHECK(orbx_lapping_ratio_test_batch_device(left, 0.7));
+    std::vector<int32_t> match(cap);
+    int ngood = 0;
+    for (int f = 0; f < NF; ++f) CHECK(orbx_lapping_matches_download(left, f, match.data(), cap, &nq, &ngood));
   }
 
   step("stereo association");
@@ -298,6 +303,46 @@ int main(int argc, char** argv) {
                                              assigned.data(), cap, &nout, &nm, &rounds));
       fprintf(stderr, "race_driver:   variant %d: %d matches in %d rounds\n", variant, nm, rounds);
     }
+  }
+
+  // the right camera of a rig: the other handle's extraction of the same batch, its own grid
+  step("two-camera forms of the projection matchers");
+  {
+    CHECK(orbx_frame_grid_batch_device(right, NF, nullptr, bounds));
+    const int nl = n[0];
+    std::vector<uint8_t> valid(nl), obs(nl), stL(cap), stR(cap);
+    std::vector<float> uvl(2 * (size_t)nl), uvr(2 * (size_t)nl), invz(nl), ang(nl), vcos(nl, 0.9995f);
+    std::vector<int32_t> oct(nl), asgL(cap), asgR(cap), l2r(cap, -1), r2l(cap, -1);
+    std::uniform_real_distribution<float> jitter(-5.f, 5.f);
+    for (int i = 0; i < nl; ++i) {
+      valid[i] = rng() % 8 != 0;
+      obs[i] = rng() % 3 != 0;
+      uvl[2 * i] = kun[i].x + jitter(rng);
+      uvl[2 * i + 1] = kun[i].y + jitter(rng);
+      uvr[2 * i] = kun[i].x + jitter(rng);
+      uvr[2 * i + 1] = kun[i].y + jitter(rng);
+      invz[i] = 0.05f + 0.001f * (float)(rng() % 100);
+      ang[i] = kun[i].angle;
+      oct[i] = kun[i].octave;
+    }
+    for (int i = 0; i < cap; ++i) {
+      stL[i] = (uint8_t)(rng() % 6 == 0 ? 1 + rng() % 2 : 0);
+      stR[i] = (uint8_t)(rng() % 6 == 0 ? 1 + rng() % 2 : 0);
+    }
+    const std::vector<uint8_t> dl = perturbed(desc.data(), nl, 24, rng);
+    int nL = 0, nR = 0, nm = 0, rounds = 0;
+    CHECK(orbx_search_by_projection_last_rig(left, right, 0, nl, valid.data(), uvl.data(), invz.data(), uvr.data(),
+                                             oct.data(), ang.data(), dl.data(), obs.data(), stL.data(), stR.data(),
+                                             15.0f, 0, 0, 1, asgL.data(), cap, &nL, asgR.data(), cap, &nR, &nm, &rounds));
+    fprintf(stderr, "race_driver:   last frame, two cameras: %d matches in %d rounds\n", nm, rounds);
+    // stereo partners: arbitrary links, so that partner writes re-open and close keypoints
+    for (int i = 0; i < nL; ++i) l2r[i] = (nR > 0 && rng() % 3 == 0) ? (int)(rng() % nR) : -1;
+    for (int i = 0; i < nR; ++i) r2l[i] = (nL > 0 && rng() % 3 == 0) ? (int)(rng() % nL) : -1;
+    CHECK(orbx_search_by_projection_points_rig(left, right, 0, nl, valid.data(), uvl.data(), oct.data(), vcos.data(),
+                                               valid.data(), uvr.data(), oct.data(), vcos.data(), dl.data(), obs.data(),
+                                               l2r.data(), r2l.data(), stL.data(), stR.data(), 4.0f, 0.9f, asgL.data(),
+                                               cap, &nL, asgR.data(), cap, &nR, &nm, &rounds));
+    fprintf(stderr, "race_driver:   map points, two cameras: %d matches in %d rounds\n", nm, rounds);
   }
 
   step("search for initialization");
