@@ -77,6 +77,7 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 // ---------------------------------------------------------------------------
 struct __attribute__((packed, aligned(4))) U4A4 { uint32_t x, y, z, w; };
 struct __attribute__((packed, aligned(4))) U3A4 { uint32_t x, y, z; };
+typedef uint32_t U3V4 __attribute__((ext_vector_type(3), aligned(4)));   // the same 12 bytes as a vector (loadable through any address space)
 #define L0_ROWS 4  // rows per lane
 
 // High 32 bits of the product of two values below 2^24 (v_mul_hi_u32_u24).
@@ -198,17 +199,33 @@ struct ResizeRows {
 // Source rows of 4 destination rows.  prev = the row tap before tys[0] (null for the first
 // step): a destination row whose upper source row is the previous destination row's lower one
 // takes that row's horizontal sums over, so its upper row is not loaded (wave-uniform test).
-__device__ __forceinline__ void resize_fetch(ResizeRows& R, const uint8_t* base, int sstride,
+// A wave-uniform plane address pinned to a pair of scalar registers, so that every access to the
+// plane is "scalar base + 32-bit lane offset" (one 32-bit add per access).  Left to itself the
+// optimiser folds the lane's offset into the base once and then redoes 64-bit row arithmetic per
+// lane for every load and store.  (The pointer is rebuilt from integers, so its address space is
+// stated.)
+#define GLOBAL_AS __attribute__((address_space(1)))
+__device__ __forceinline__ const GLOBAL_AS uint8_t* uniform_base(const uint8_t* base) {
+  const uint64_t a = (uint64_t)(uintptr_t)base;
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
+  return (const GLOBAL_AS uint8_t*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+}
+
+// base: the plane's first interior row at the interior's first column, the same for the whole
+// wave; laneOff: the lane's byte offset in a row.  Kept apart so that a row's address is a scalar
+// base plus a 32-bit lane offset (no 64-bit vector arithmetic per load).
+__device__ __forceinline__ void resize_fetch(ResizeRows& R, const GLOBAL_AS uint8_t* base, uint32_t laneOff, int sstride,
                                              const Tap* tys, const Tap* prev) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     // one 12-byte load per source row (dword-aligned)
     const Tap* before = r > 0 ? tys + r - 1 : prev;
     if (!(before && before->s1 == tys[r].s0)) {
-      const U3A4 a = *(const U3A4*)(base + (size_t)tys[r].s0 * sstride);
+      const U3V4 a = *(const GLOBAL_AS U3V4*)(base + (laneOff + (uint32_t)tys[r].s0 * (uint32_t)sstride));
       R.a[r][0] = a.x; R.a[r][1] = a.y; R.a[r][2] = a.z;
     }
-    const U3A4 b = *(const U3A4*)(base + (size_t)tys[r].s1 * sstride);
+    const U3V4 b = *(const GLOBAL_AS U3V4*)(base + (laneOff + (uint32_t)tys[r].s1 * (uint32_t)sstride));
     R.b[r][0] = b.x; R.b[r][1] = b.y; R.b[r][2] = b.z;
     // (b * (H >> 4)) >> 16 is the high word of the 24-bit product (b << 12) * (H & ~15)
     R.wy0[r] = (uint32_t)(int)tys[r].w0 << 12;
@@ -269,7 +286,8 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const uint8_t* __restrict__ 
   const ColRec cr = colrec[c];
   if (!(cr.deltas & 0x8000)) return;   // border column: done by the border waves
   const int sh = (ORBX_EDGE + (int)cr.sxa) & 3;   // planes and rows are 64-byte aligned
-  const uint8_t* base = src + (size_t)f * splane + (size_t)ORBX_EDGE * sstride + (ORBX_EDGE + (int)cr.sxa - sh);
+  const GLOBAL_AS uint8_t* base = uniform_base(src + (size_t)f * splane + (size_t)ORBX_EDGE * sstride);
+  const uint32_t laneOff = (uint32_t)(ORBX_EDGE + (int)cr.sxa - sh);   // >= 0: a main column's taps lie inside the row
   uint32_t sel[4], wp[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -278,22 +296,30 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const uint8_t* __restrict__ 
     wp[k] = (2048u - cr.w1[k]) | ((uint32_t)cr.w1[k] << 16);  // (left, right) weights
   }
   const uint32_t keep = cr.nvalid >= 4 ? 0xFFFFFFFFu : ((1u << (8 * cr.nvalid)) - 1u);
-  uint8_t* dcol = dst + (size_t)f * dplane + 4 * c;
+  GLOBAL_AS uint8_t* dframe = (GLOBAL_AS uint8_t*)uniform_base(dst + (size_t)f * dplane);
+  const uint32_t dOff = 4u * (uint32_t)c;
   const int pyBase = (by * (int)blockDim.y + wave) * rowsPerWave;
   if (pyBase >= prows) return;
   // the row taps of all steps first: wave-uniform, read before any store so that they can
   // come through the scalar cache
+  // (made scalar explicitly: with the taps in scalar registers a row's address is a scalar base
+  // plus the lane's 32-bit offset, and the row weights are scalar operands)
   Tap tys[rowsPerWave];
 #pragma unroll
-  for (int r = 0; r < rowsPerWave; ++r) tys[r] = ytab[min(pyBase + r, prows - 1)];
+  for (int r = 0; r < rowsPerWave; ++r) {
+    const uint2 t = *(const uint2*)&ytab[min(pyBase + r, prows - 1)];
+    const uint32_t ss = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.x), ww = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.y);
+    tys[r].s0 = (uint16_t)(ss & 0xFFFFu); tys[r].s1 = (uint16_t)(ss >> 16);
+    tys[r].w0 = (int16_t)(ww & 0xFFFFu); tys[r].w1 = (int16_t)(ww >> 16);
+  }
   ResizeRows buf[2];
-  resize_fetch(buf[0], base, sstride, tys, nullptr);
+  resize_fetch(buf[0], base, laneOff, sstride, tys, nullptr);
   uint32_t hprev[4] = {0u, 0u, 0u, 0u};   // horizontal sums (low 4 bits cleared) of the previous row's lower source row
 #pragma unroll
   for (int g = 0; g < GROUPS; ++g) {
     const int py0 = pyBase + 4 * g;
     if (py0 >= prows) break;
-    if (g + 1 < GROUPS) resize_fetch(buf[(g + 1) & 1], base, sstride, tys + 4 * (g + 1), tys + 4 * g + 3);
+    if (g + 1 < GROUPS) resize_fetch(buf[(g + 1) & 1], base, laneOff, sstride, tys + 4 * (g + 1), tys + 4 * g + 3);
     const ResizeRows& cur = buf[g & 1];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -320,7 +346,8 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const uint8_t* __restrict__ 
           v[k] = (mul_hi_u24(cur.wy0[r], h0[k]) + mul_hi_u24(cur.wy1[r], h1[k]) + 2u) >> 2;
           hprev[k] = h1[k];
         }
-        *(uint32_t*)(dcol + (size_t)py * pstride) = (v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24)) & keep;
+        *(GLOBAL_AS uint32_t*)(dframe + (dOff + (uint32_t)py * (uint32_t)pstride)) =
+            (v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24)) & keep;
       }
     }
   }
