@@ -346,8 +346,11 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const uint8_t* __restrict__ 
           v[k] = (mul_hi_u24(cur.wy0[r], h0[k]) + mul_hi_u24(cur.wy1[r], h1[k]) + 2u) >> 2;
           hprev[k] = h1[k];
         }
-        *(GLOBAL_AS uint32_t*)(dframe + (dOff + (uint32_t)py * (uint32_t)pstride)) =
-            (v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24)) & keep;
+        // the four results (each <= 255) into one dword: two byte permutes and an or (left to
+        // itself the optimiser rebuilds the shifts as multiply-adds with masks, twelve instructions)
+        const uint32_t p01 = __builtin_amdgcn_perm(v[1], v[0], 0x0c0c0400u);
+        const uint32_t p23 = __builtin_amdgcn_perm(v[3], v[2], 0x04000c0cu);
+        *(GLOBAL_AS uint32_t*)(dframe + (dOff + (uint32_t)py * (uint32_t)pstride)) = (p01 | p23) & keep;
       }
     }
   }
