@@ -390,7 +390,10 @@ int orbx_image_bounds(const orbx_pinhole* cam, int width, int height, float* bou
  * ex, on the keypoints where the extraction left them.  Asynchronous on the
  * handle's stream.  The grid is a CSR over cells c = posX*48 + posY
  * (mGrid[posX][posY]); a cell's keypoint indices are ascending, as push_back
- * leaves them. */
+ * leaves them.  Bounds without extent in x or y are refused
+ * (ORBX_ERR_BAD_ARG): distortion strong enough to fold the image's corners onto
+ * one point gives such bounds, and the reference would go on with an infinite
+ * cell size (Frame.cc:193-196). */
 int orbx_frame_grid_batch_device(orbx_extractor* ex, int n_frames, const orbx_pinhole* cam,
                                  const float* bounds);
 /* Device buffers of the last grid call: mvKeysUn [n_frames][cap] (28 B each),

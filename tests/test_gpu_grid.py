@@ -78,6 +78,12 @@ def test_frame_grid_argument_errors():
     ex(orbx.textured_frame(1, 320, 240), None, (0, 0))
     with pytest.raises(OrbxError):                      # empty bounds
         grid.frame_grid_batch(ex, 1, None, [0, 0, 0, 240])
+    # distortion that folds all four corners onto the principal point: bounds without extent
+    folded = grid.pinhole(155.4, 157.99, 132.5, 203.0, -0.336549, -0.053964, -0.000485, 0.000557, 0.01)
+    b = grid.image_bounds(folded, 259, 410)
+    assert not (b[1] > b[0] and b[3] > b[2])
+    with pytest.raises(OrbxError):
+        grid.frame_grid_batch(ex, 1, folded, b)
     with pytest.raises(OrbxError):                      # more frames than extracted
         grid.frame_grid_batch(ex, 2, None, [0, 320, 0, 240])
     with pytest.raises(OrbxError):                      # query before any grid call
