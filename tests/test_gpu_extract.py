@@ -341,6 +341,50 @@ def test_host_batch_pipeline_groups(oracle, pinned, monkeypatch):
         _l().orbx_host_free(h)
 
 
+@pytest.mark.parametrize("pinned", [False, True])
+def test_single_frame_host_call(oracle, pinned):
+    """orbx_extract, the call Frame::ExtractORB makes: one frame from page-locked or ordinary
+    memory, packed or strided rows, results equal to the oracle; an output array that is too small
+    gives the count and ORBX_ERR_CAPACITY."""
+    import ctypes as C
+    from orb_slam3_amd._lib import lib, check, KEYPOINT_DTYPE, ORBX_ERR_CAPACITY
+    W, H, stride = 376, 240, 400
+    frame = orbx.textured_frame(77, W, H)
+    st, rmono, rk, rd = oracle.Extractor(400, 1.2, 6, 20, 7).extract(frame, (100, 250))
+    assert st == 0
+    ex = orbx.ORBextractor(400, 1.2, 6, 20, 7)
+    cap = ex.max_keypoints()
+    holds = []
+    if pinned:
+        img, h0 = _pinned_array((H, stride), np.uint8)
+        holds.append(h0)
+    else:
+        img = np.zeros((H, stride), np.uint8)
+    img[:] = 0xA5
+    img[:, :W] = frame
+    packed = np.ascontiguousarray(frame)
+    n, mono = C.c_int32(), C.c_int32()
+    for src, use_stride in ((img, stride), (packed, W)):
+        kps = np.zeros(cap, KEYPOINT_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        check(lib().orbx_extract(ex._h, C.c_void_p(src.ctypes.data), W, H, use_stride, 100, 250,
+                                 kps.ctypes.data_as(C.c_void_p), desc.ctypes.data_as(C.c_void_p), cap, C.byref(n),
+                                 C.byref(mono)), "orbx_extract")
+        assert n.value == len(rk) and mono.value == rmono, use_stride
+        for fld in ("x", "y", "size", "response", "octave", "class_id"):
+            assert np.array_equal(kps[fld][:n.value], rk[fld]), (use_stride, fld)
+        assert np.array_equal(desc[:n.value], rd), use_stride
+    small = max(1, len(rk) // 2)
+    kps = np.zeros(small, KEYPOINT_DTYPE)
+    desc = np.zeros((small, 32), np.uint8)
+    status = lib().orbx_extract(ex._h, C.c_void_p(packed.ctypes.data), W, H, W, 100, 250, kps.ctypes.data_as(C.c_void_p),
+                                desc.ctypes.data_as(C.c_void_p), small, C.byref(n), C.byref(mono))
+    assert status == ORBX_ERR_CAPACITY and n.value == len(rk)
+    ex.close()
+    for h in holds:
+        lib().orbx_host_free(h)
+
+
 def test_two_part_batches_back_to_back(oracle):
     """Batches large enough to run as two parts on two streams, enqueued back to back without a
     synchronisation in between (the second part of one batch may still run while the first part of
