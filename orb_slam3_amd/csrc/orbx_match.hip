@@ -361,7 +361,6 @@ __global__ __launch_bounds__(256) void k_knn2_mfma_frames(const uint32_t* __rest
 typedef int km_v8i __attribute__((ext_vector_type(8)));
 typedef float km_v16f __attribute__((ext_vector_type(16)));
 #define KF_SCALE_ONE 0x7f7f7f7f               // E8M0 scale bytes: 2^(127 - 127)
-#define KF_BIAS 512.0f                        // start value of the accumulators (see the scan)
 
 // the 32 bits of a word as 32 e2m1 nibbles, 1.0 where the bit is set
 __device__ __forceinline__ km_v4i bits_to_fp4(uint32_t w) {
@@ -387,7 +386,7 @@ __device__ __forceinline__ void knn2_fp4_scan(const uint32_t* __restrict__ q, in
   const int r = lane & 31, h = lane >> 5;
   // ---- the wave's queries as B operands (+1 / -1), and their popcounts --------
   km_v4i bq[KF_NQT][4];
-  float qpopb[KF_NQT];   // popcount - bias: distance = result + popcount - bias
+  float qpop[KF_NQT];    // popcount: distance = result + popcount
 #pragma unroll
   for (int qt = 0; qt < KF_NQT; ++qt) {
     const int qi = qblock * KF_QPB + (wave * KF_NQT + qt) * 32 + r;
@@ -402,20 +401,19 @@ __device__ __forceinline__ void knn2_fp4_scan(const uint32_t* __restrict__ q, in
       const km_v4i e = bits_to_fp4(h ? w[2 * s + 1] : w[2 * s]);
       bq[qt][s].x = fp4_pm1(e.x); bq[qt][s].y = fp4_pm1(e.y); bq[qt][s].z = fp4_pm1(e.z); bq[qt][s].w = fp4_pm1(e.w);
     }
-    qpopb[qt] = (float)pc - KF_BIAS;
+    qpop[qt] = (float)pc;
   }
   uint32_t k0[KF_NQT], k1[KF_NQT];
-  // The accumulators start at KF_BIAS instead of zero, so every result (bias + product, product in
-  // [-256, 256]) is a positive float and its bit pattern orders like its value: the smallest of a
-  // lane's 16 results comes out of integer min3 instructions (the float ones first have to quiet
-  // possible NaNs).  A row can enter when its result is below thd = bias + second-best distance -
-  // popcount, kept as a bit pattern too.
-  uint32_t thd[KF_NQT];
+  // The accumulators start at zero (an inline operand of the instruction: no registers hold a start
+  // vector), so a result is the product itself, a small integer in [-256, 256] held in a float; the
+  // smallest of a lane's 16 results comes out of float min3 instructions.  A row can enter when its
+  // result is below thd = second-best distance - popcount.
+  float thd[KF_NQT];
 #pragma unroll
-  for (int qt = 0; qt < KF_NQT; ++qt) { k0[qt] = 0xFFFFFFFFu; k1[qt] = 0xFFFFFFFFu; thd[qt] = __float_as_uint(KF_BIAS + 1024.f); }
+  for (int qt = 0; qt < KF_NQT; ++qt) { k0[qt] = 0xFFFFFFFFu; k1[qt] = 0xFFFFFFFFu; thd[qt] = 1024.f; }
   km_v16f zero;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) zero[i] = KF_BIAS;
+  for (int i = 0; i < 16; ++i) zero[i] = 0.0f;
 
   // ---- train tiles, KF_SUB of them per stage (one workgroup barrier per stage) ------
   // staging: this thread's row of a tile and word of the row; word sw = 2 s + h goes to the
@@ -468,9 +466,9 @@ __device__ __forceinline__ void knn2_fp4_scan(const uint32_t* __restrict__ q, in
       bool anyAll = false;
 #pragma unroll
       for (int qt = 0; qt < KF_NQT; ++qt) {
-        uint32_t mn = __float_as_uint(acc[qt][0]);
+        float mn = acc[qt][0];
 #pragma unroll
-        for (int i = 1; i < 16; ++i) mn = min(mn, __float_as_uint(acc[qt][i]));
+        for (int i = 1; i < 16; ++i) mn = fminf(mn, acc[qt][i]);
         any[qt] = mn < thd[qt];
         anyAll |= any[qt];
       }
@@ -487,14 +485,14 @@ __device__ __forceinline__ void knn2_fp4_scan(const uint32_t* __restrict__ q, in
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const int row = rowBase + (i & 3) + 8 * (i >> 2);
-            const uint32_t dist = (uint32_t)(int)(qpopb[qt] + acc[qt][i]);
+            const uint32_t dist = (uint32_t)(int)(qpop[qt] + acc[qt][i]);
             const uint32_t key = (whole || row < len) ? ((dist << KNN_IDX_BITS) | (uint32_t)row) : 0xFFFFFFFFu;
             const uint32_t hi = max(k0[qt], key);
             k0[qt] = min(k0[qt], key);
             k1[qt] = min(k1[qt], hi);
           }
           // (an empty second slot gives a distance field of 1023: above every result)
-          thd[qt] = __float_as_uint((float)(int)(k1[qt] >> KNN_IDX_BITS) - qpopb[qt]);
+          thd[qt] = (float)(int)(k1[qt] >> KNN_IDX_BITS) - qpop[qt];
         }
       }
     }

@@ -266,7 +266,7 @@ inline sim_v16i mfma_i32_32x32x32_i8(int site, sim_v4i a, sim_v4i b, sim_v16i c)
 #define __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, x, y, z) hostsim::mfma_i32_32x32x32_i8(__LINE__, (a), (b), (c))
 
 // v_mfma_scale_f32_32x32x64_f8f6f4 with both operands FP4 (e2m1; cbsz = blgp = 4) and both block
-// scales 2^0: D = A (32 x 64) * B (64 x 32) + C in f32.  Lane l holds row l & 31 of A and column
+// scales the same power of two in every lane (E8M0 bytes, 2^(e - 127)): D = scale_a scale_b A (32 x 64) * B (64 x 32) + C in f32.  Lane l holds row l & 31 of A and column
 // l & 31 of B for the 32 k values 32 (l >> 5) .. + 31, one per nibble of its first four dwords;
 // C / D as for the 32 x 32 integer form.  Other formats and scales are not emulated.
 typedef int sim_v8i __attribute__((ext_vector_type(8)));
@@ -277,8 +277,11 @@ inline float fp4_e2m1(unsigned c) {
 }
 inline sim_v16f mfma_scale_f32_32x32x64_fp4(int site, sim_v8i a, sim_v8i b, sim_v16f c, int cbsz, int blgp, int opa,
                                             int sa, int opb, int sb) {
-  if (cbsz != 4 || blgp != 4 || opa != 0 || opb != 0 || (sa & 0xFF) != 0x7f || (sb & 0xFF) != 0x7f)
-    fail("scaled mfma: only FP4 operands with unit scales are emulated", site);
+  if (cbsz != 4 || blgp != 4 || opa != 0 || opb != 0) fail("scaled mfma: only FP4 operands are emulated", site);
+  for (int k = 1; k < 4; ++k)
+    if (((sa >> (8 * k)) & 0xFF) != (sa & 0xFF) || ((sb >> (8 * k)) & 0xFF) != (sb & 0xFF))
+      fail("scaled mfma: the four scale bytes of a lane must be equal here", site);
+  const float scale = ldexpf(1.0f, (int)(sa & 0xFF) - 127 + (int)(sb & 0xFF) - 127);
   uint64_t av[2][64], bv[2][64];
   uint64_t mask = 0;
   for (int half = 0; half < 2; ++half) {
@@ -302,7 +305,7 @@ inline sim_v16f mfma_scale_f32_32x32x64_fp4(int site, sim_v8i a, sim_v8i b, sim_
         const float bb = fp4_e2m1((unsigned)(bv[j >> 4][n + 32 * hh] >> (4 * (j & 15))) & 15u);
         sum += ab * bb;
       }
-    d[i] += sum;
+    d[i] += scale * sum;
   }
   return d;
 }
