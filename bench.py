@@ -214,6 +214,9 @@ def hamming_bench(torch, orbx, dev, world, rank, nq=1 << 20, nt_per_gpu=1_250_00
                         "frac_of_measured_instruction_rate": pairs / (17.3e12 * world),
                         "measured_instruction_rate": "17.3 T pairs/s: back-to-back instructions, two waves per SIMD "
                                                      "(tools/probe/fp4_hamming_probe.hip, profiles/r3_fp4_hamming_probe.txt)",
+                        "rate_of_the_kernels_instruction_pattern": "11.5 T pairs/s in the same probe: two accumulators per wave "
+                                                                   "restarted every four instructions, rotating random operands, a "
+                                                                   "16-value min3 chain per accumulator, no memory, four waves per SIMD",
                         "times_the_int8_peak": pairs * 512 / (MFMA_I8_PEAK_OPS * world),
                         "times_the_vector_alu_roof": pairs * 16 / (VALU_PEAK_LANE_OPS * world)}}
     if os.environ.get("ORBX_KNN2_I8") == "1":
