@@ -78,6 +78,21 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 struct __attribute__((packed, aligned(4))) U4A4 { uint32_t x, y, z, w; };
 struct __attribute__((packed, aligned(4))) U3A4 { uint32_t x, y, z; };
 typedef uint32_t U3V4 __attribute__((ext_vector_type(3), aligned(4)));   // the same 12 bytes as a vector (loadable through any address space)
+typedef uint32_t U4V4 __attribute__((ext_vector_type(4), aligned(4)));
+
+// A wave-uniform plane address pinned to a pair of scalar registers, so that every access to the
+// plane is "scalar base + 32-bit lane offset" (one 32-bit add per access).  Left to itself the
+// optimiser folds the lane's offset into the base once and then redoes 64-bit row arithmetic per
+// lane for every load and store.  (The pointer is rebuilt from integers, so its address space is
+// stated.)
+#define GLOBAL_AS __attribute__((address_space(1)))
+__device__ __forceinline__ const GLOBAL_AS uint8_t* uniform_base(const uint8_t* base) {
+  const uint64_t a = (uint64_t)(uintptr_t)base;
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
+  return (const GLOBAL_AS uint8_t*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+}
+
 #define L0_ROWS 4  // rows per lane
 
 // High 32 bits of the product of two values below 2^24 (v_mul_hi_u32_u24).
@@ -126,28 +141,31 @@ __global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t* __restrict__ 
   const int ghi = (W - 1) / 16;
   if (bx < nbx) {
     const int g = bx * 64 + threadIdx.x;
-    const int py0 = (by * (int)blockDim.y + (int)threadIdx.y) * L0_ROWS;
+    // (a wave's rows are the same for all its lanes: said explicitly, so that row arithmetic is
+    // scalar and every access is a scalar base plus a 32-bit lane offset)
+    const int py0 = (by * (int)blockDim.y + __builtin_amdgcn_readfirstlane((int)threadIdx.y)) * L0_ROWS;
     if (g < 2 || g > ghi) return;
-    const int P = g * 16;
-    uint8_t* fdst = dst + (size_t)f * dplane + P;
+    const uint32_t P = (uint32_t)g * 16u;
+    const GLOBAL_AS uint8_t* sbase = uniform_base(fimg);
+    GLOBAL_AS uint8_t* dbase = (GLOBAL_AS uint8_t*)uniform_base(dst + (size_t)f * dplane);
 #pragma unroll
     for (int r = 0; r < L0_ROWS; ++r) {
       const int py = py0 + r;
       if (py >= prows) break;
       const int sy = reflect101(py - ORBX_EDGE, H);
-      // (the aligned address is formed from the offset, not by masking the pointer's integer
-      // value: such a pointer would be accessed with flat instead of global loads)
-      const size_t off = (size_t)sy * istride + (P - ORBX_EDGE);
-      const int sh = (int)(((uintptr_t)fimg + off) & 3);
-      const uint8_t* ap = fimg + (off - sh);
-      const U4A4 v = *(const U4A4*)ap;
-      const uint32_t v4 = *(const uint32_t*)(ap + 16);
-      uint4 out;
+      // the 16 pixels start at byte rowOff + P - EDGE of the frame; loads are dword-aligned (P is
+      // a multiple of 16, so the misalignment is the same for all lanes of the row)
+      const uint32_t rowOff = (uint32_t)sy * (uint32_t)istride - (uint32_t)ORBX_EDGE;
+      const uint32_t sh = ((uint32_t)(uintptr_t)fimg + rowOff) & 3u;
+      const uint32_t voff = rowOff - sh + P;
+      const U4V4 v = *(const GLOBAL_AS U4V4*)(sbase + voff);
+      const uint32_t v4 = *(const GLOBAL_AS uint32_t*)(sbase + voff + 16u);
+      U4V4 out;
       out.x = __builtin_amdgcn_alignbyte(v.y, v.x, sh);
       out.y = __builtin_amdgcn_alignbyte(v.z, v.y, sh);
       out.z = __builtin_amdgcn_alignbyte(v.w, v.z, sh);
       out.w = __builtin_amdgcn_alignbyte(v4, v.w, sh);
-      *(uint4*)(fdst + (size_t)py * pstride) = out;
+      *(GLOBAL_AS U4V4*)(dbase + ((uint32_t)py * (uint32_t)pstride + P)) = out;
     }
   } else {
     // border block: one lane per (row, dword) of the left 8 and the right border dwords
@@ -199,19 +217,6 @@ struct ResizeRows {
 // Source rows of 4 destination rows.  prev = the row tap before tys[0] (null for the first
 // step): a destination row whose upper source row is the previous destination row's lower one
 // takes that row's horizontal sums over, so its upper row is not loaded (wave-uniform test).
-// A wave-uniform plane address pinned to a pair of scalar registers, so that every access to the
-// plane is "scalar base + 32-bit lane offset" (one 32-bit add per access).  Left to itself the
-// optimiser folds the lane's offset into the base once and then redoes 64-bit row arithmetic per
-// lane for every load and store.  (The pointer is rebuilt from integers, so its address space is
-// stated.)
-#define GLOBAL_AS __attribute__((address_space(1)))
-__device__ __forceinline__ const GLOBAL_AS uint8_t* uniform_base(const uint8_t* base) {
-  const uint64_t a = (uint64_t)(uintptr_t)base;
-  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
-  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
-  return (const GLOBAL_AS uint8_t*)(uintptr_t)(((uint64_t)hi << 32) | lo);
-}
-
 // base: the plane's first interior row at the interior's first column, the same for the whole
 // wave; laneOff: the lane's byte offset in a row.  Kept apart so that a row's address is a scalar
 // base plus a 32-bit lane offset (no 64-bit vector arithmetic per load).
