@@ -114,7 +114,9 @@ int orbx_host_free(void* p);
  * images (height*stride bytes each) in device memory.  Work is enqueued on the
  * handle's stream and the call returns without waiting; results stay in the
  * handle's device buffers (orbx_batch_results_device) until the next call.
- * orbx_sync waits for completion. */
+ * orbx_sync waits for completion.  One frame (height*stride bytes) and one
+ * padded level-0 plane must each stay below 4 GiB: the kernels address them
+ * with 32-bit offsets, and larger ones return ORBX_ERR_UNSUPPORTED. */
 int orbx_extract_batch_device(orbx_extractor* ex, int n_frames, const uint8_t* d_imgs, int width,
                               int height, int stride, int lap0, int lap1);
 int orbx_sync(orbx_extractor* ex);

@@ -815,8 +815,15 @@ int orbx_extractor::joinParts() {
   return ORBX_OK;
 }
 
+// The pyramid kernels address a frame and a plane with 32-bit byte offsets from a per-frame base.
+static bool offsets_fit_32(const orbx::Plan& hp, int istride) {
+  return (unsigned long long)istride * (unsigned long long)hp.H < (1ull << 32) &&
+         (unsigned long long)hp.lv[0].pstride * (unsigned long long)hp.lv[0].prows < (1ull << 32);
+}
+
 int orbx_extractor::run(const uint8_t* d_images, int istride, size_t iframe, int nframes, int lap0,
                         int lap1) {
+  if (!offsets_fit_32(hp, istride)) return ORBX_ERR_UNSUPPORTED;
   hipStream_t s = stream;
   const bool prof = profiling;
   lastParts = 0;
@@ -900,6 +907,7 @@ int orbx_extractor::run(const uint8_t* d_images, int istride, size_t iframe, int
 int orbx_extractor::enqueuePart(int pk, hipStream_t m, hipStream_t side, hipEvent_t fork, hipEvent_t join,
                                 int f0, int n, hipEvent_t pyrDone, const uint8_t* d_images, int istride,
                                 size_t iframe, int lap0, int lap1) {
+  if (!offsets_fit_32(hp, istride)) return ORBX_ERR_UNSUPPORTED;
   orbx::launch_pyramid(hp, d_images, istride, iframe, d_pyr, f0, n, m);
   if (pyrDone) HIP_TRY(hipEventRecord(pyrDone, m));
   const bool planes = !hp.blur_in_describe;   // the full-plane blur launch exists only in that schedule
