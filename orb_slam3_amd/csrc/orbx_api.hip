@@ -21,6 +21,8 @@
 #include "orbx_bow.h"
 
 namespace orbx {
+void launch_export_one(const int* d_n, const int* d_mono, const float* d_kps, const uint8_t* d_desc, int cap,
+                       int* hcnt, void* hk, void* hd, hipStream_t s);
 void launch_pyramid(const Plan& hp, const uint8_t* d_img, int istride, size_t iframe, uint8_t* d_pyr,
                     int f0, int nframes, hipStream_t s);
 void launch_knn2_frames(const uint8_t* descL, int capL, const int* nL, const int* monoL, const uint8_t* descR,
@@ -631,6 +633,23 @@ int orbx_extractor::buildPlan(int W, int H) {
       hp.oct_ws_bytes = (uint32_t)((orbx::octree_lds_bytes(hp) + 255) / 256 * 256);
     }
   }
+  {
+    // k_octree_team: batches too small to fill the chip with one wave per (frame, level)
+    // (measured at 752 x 480, 1000 features: 0.117 against 0.156 ms for one frame, 0.296 against
+    // 0.316 ms for 64, 0.515 against 0.471 ms for 128).  Its key arrays take what is left of
+    // 120 KB of LDS beside the node arrays.
+    hp.oct_team_keys = 0;
+    hp.oct_team_frames = 64;
+    if (const char* e = std::getenv("ORBX_OCT_TEAM")) {   // timing / test knob, results do not change
+      const long v = std::strtol(e, nullptr, 10);
+      if (v >= 0 && v <= 1 << 20) hp.oct_team_frames = (int)v;
+    }
+    if (!hp.oct_ws_bytes && hp.oct_team_frames > 0) {
+      const long fixed = (long)nodesCap * 80 + (long)(cellsMax + 1) * 4 + 256;
+      const long keys = std::min((120L * 1024 - fixed) / 20, 6144L) / 8 * 8;
+      if (keys >= 512) hp.oct_team_keys = (int)keys;
+    }
+  }
   maxKeypoints = selOff;
   pyr_bytes = pyrOff;
 
@@ -1204,9 +1223,11 @@ bool is_pinned_host(const void* p, size_t bytes) {
 }  // namespace
 
 // One frame from host memory, the call Frame::ExtractORB makes (core/src/Frame.cc:461-470): no
-// groups, no helper streams, no packing threads - image in, kernels, counts and results out on the
-// handle's own stream with one synchronisation.  The results travel at full slot capacity beside
-// the counts (one wait instead of count-then-results) unless that is more than a few hundred KB.
+// groups, no helper streams, no packing threads and no copy engines - the image is packed into the
+// handle's page-locked buffer, which the first pyramid kernel reads over the bus; a last small
+// kernel writes the counts and the n records into page-locked memory; one synchronisation.
+// (Asking the runtime whether the caller's image is page-locked costs ten times what packing a
+// frame of a few hundred KB costs, so only large frames ask, and those go through a copy.)
 static int extract_one(orbx_extractor* ex, const uint8_t* img, int width, int height, int stride, int lap0,
                        int lap1, orbx_keypoint* kps, uint8_t* desc, int cap, int* n_out, int* mono_out) {
   auto& last_hip_error = ex->last_hip_error;
@@ -1216,7 +1237,8 @@ static int extract_one(orbx_extractor* ex, const uint8_t* img, int width, int he
   const int kc = ex->hp.kp_cap;
   const int ccap = std::min(cap, kc);
   const bool wantK = kps && ccap > 0, wantD = desc && ccap > 0;
-  const bool pinnedIn = is_pinned_host(img, srcBytes);
+  const bool small = frameBytes <= ((size_t)2 << 20);
+  const bool pinnedIn = !small && is_pinned_host(img, srcBytes);
   int st = ex->ensureHostStaging(!pinnedIn, true);
   if (st != ORBX_OK) return st;
   const uint8_t* src = img;
@@ -1228,30 +1250,26 @@ static int extract_one(orbx_extractor* ex, const uint8_t* img, int width, int he
     src = hin;
     sstride = width;
   }
-  if (sstride == width) HIP_TRY(hipMemcpyAsync(ex->d_img, src, frameBytes, hipMemcpyHostToDevice, s));
-  else HIP_TRY(hipMemcpy2DAsync(ex->d_img, width, src, sstride, width, height, hipMemcpyHostToDevice, s));
-  st = ex->run(ex->d_img, width, frameBytes, 1, lap0, lap1);
+  void* srcDev = nullptr;
+  if (small && hipHostGetDevicePointer(&srcDev, (void*)src, 0) == hipSuccess && srcDev) {
+    st = ex->run((const uint8_t*)srcDev, sstride, (size_t)sstride * height, 1, lap0, lap1);
+  } else {
+    (void)hipGetLastError();
+    if (sstride == width) HIP_TRY(hipMemcpyAsync(ex->d_img, src, frameBytes, hipMemcpyHostToDevice, s));
+    else HIP_TRY(hipMemcpy2DAsync(ex->d_img, width, src, sstride, width, height, hipMemcpyHostToDevice, s));
+    st = ex->run(ex->d_img, width, frameBytes, 1, lap0, lap1);
+  }
   if (st != ORBX_OK) return st;
   int* hn = ex->h_cnt[0];
   uint8_t* hk = ex->h_out[0];
   uint8_t* hd = hk + (size_t)ex->groupFrames * kc * 28;
-  HIP_TRY(hipMemcpyAsync(hn, ex->d_n, 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(hn + 1, ex->d_mono, 4, hipMemcpyDeviceToHost, s));
-  const bool eager = (size_t)ccap * 60 <= (384u << 10);
-  if (eager) {
-    if (wantK) HIP_TRY(hipMemcpyAsync(hk, ex->d_kps, (size_t)ccap * 28, hipMemcpyDeviceToHost, s));
-    if (wantD) HIP_TRY(hipMemcpyAsync(hd, ex->d_desc, (size_t)ccap * 32, hipMemcpyDeviceToHost, s));
-  }
+  orbx::launch_export_one(ex->d_n, ex->d_mono, ex->d_kps, ex->d_desc, ccap, hn, hk, hd, s);
+  HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(s));
   const int n = hn[0];
   if (n_out) *n_out = n;
   if (mono_out) *mono_out = hn[1];
   if (n > cap) return ORBX_ERR_CAPACITY;
-  if (n > 0 && !eager) {
-    if (wantK) HIP_TRY(hipMemcpyAsync(hk, ex->d_kps, (size_t)n * 28, hipMemcpyDeviceToHost, s));
-    if (wantD) HIP_TRY(hipMemcpyAsync(hd, ex->d_desc, (size_t)n * 32, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-  }
   if (n > 0) {
     if (wantK) std::memcpy(kps, hk, (size_t)n * 28);
     if (wantD) std::memcpy(desc, hd, (size_t)n * 32);

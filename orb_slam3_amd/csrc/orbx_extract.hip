@@ -1428,6 +1428,314 @@ __global__ __launch_bounds__(64) void k_octree(const Plan* __restrict__ plan,
 }
 
 // ---------------------------------------------------------------------------
+// The same tree built by a team of NW waves, for batches too small to fill the chip with one
+// wave per (frame, level): there the longest tree is the whole stage, and one wave spends it
+// waiting for LDS.  Every key is handled by one thread in every pass instead of one node per
+// lane: a prefix count of the keys per quadrant over the key array in its current order (four
+// 16-bit counters packed in two words, one scan for all nodes at once) gives a node's four
+// counts as the difference between its two ends, and a key's place in its child as its own
+// prefix minus the one at its node's start - the stable partition of every node of a pass in
+// one sweep.  own[] names the node (list position) that holds a key, OWN_NONE once that node
+// is final.  Steps that are short and serial by nature (the list of nodes to split, the
+// creation indices, the rebuilt list, the records) are executed by every wave on its own with
+// identical results; the sort of the final rounds runs on wave 0.
+// Requires at most four roots and a key count within the LDS buffers; the caller falls back to
+// the one-wave form otherwise.
+// ---------------------------------------------------------------------------
+#define OWN_NONE 0xFFFFu
+
+struct TeamState {
+  unsigned short* ownCur;   // per key position
+  unsigned short* ownNxt;
+  uint2* pref;              // per key position + 1: keys before it per class, (c0 | c1 << 16, c2 | c3 << 16)
+  short* tOf;               // per list position: index in ord, -1 = not split in this pass
+  uint2* wtot;              // 2 x NW wave totals of the scan
+};
+
+__device__ __forceinline__ int pref_field(uint2 v, int q) {
+  return (int)(((q & 2) ? v.y : v.x) >> ((q & 1) * 16)) & 0xFFFF;
+}
+
+// pref[i] = number of keys j < i of each class, cls(j) in {0,1,2,3} or -1 (not counted), for
+// i in [0, total].  Thread tid takes four consecutive keys of every block of 4 * T.
+template <int NW, class F>
+__device__ __forceinline__ void team_prefix(int total, uint2* pref, uint2* wtot, F cls) {
+  constexpr int T = 64 * NW;
+  const int lane = lane_id(), w = (int)threadIdx.y, tid = w * 64 + lane;
+  uint32_t carryLo = 0, carryHi = 0;
+  int par = 0;
+  for (int cb = 0; cb <= total; cb += 4 * T, par ^= 1) {
+    const int i0 = cb + 4 * tid;
+    uint32_t lo[4], hi[4], accLo = 0, accHi = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int q = i0 + j < total ? cls(i0 + j) : -1;
+      lo[j] = accLo;
+      hi[j] = accHi;
+      accLo += (q == 0 ? 1u : 0u) + (q == 1 ? 0x10000u : 0u);
+      accHi += (q == 2 ? 1u : 0u) + (q == 3 ? 0x10000u : 0u);
+    }
+    const uint32_t sLo = (uint32_t)wave_incl_scan((int)accLo), sHi = (uint32_t)wave_incl_scan((int)accHi);
+    if (lane == 63) wtot[par * NW + w] = make_uint2(sLo, sHi);
+    __syncthreads();
+    uint32_t bLo = carryLo + sLo - accLo, bHi = carryHi + sHi - accHi;
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) {
+      const uint2 t = wtot[par * NW + ww];
+      if (ww < w) { bLo += t.x; bHi += t.y; }
+      carryLo += t.x;
+      carryHi += t.y;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (i0 + j <= total) pref[i0 + j] = make_uint2(bLo + lo[j], bHi + hi[j]);
+  }
+  __syncthreads();
+}
+
+template <int NW>
+__device__ __forceinline__ void team_octree_level(const LevelDesc& L, OctState st, TeamState ts,
+                                                  orbx_sort::elem_t* rec, const int* cellpref,
+                                                  const uint32_t* __restrict__ candL, int nc, int total,
+                                                  uint32_t* __restrict__ out, int* __restrict__ selCountSlot) {
+  constexpr int T = 64 * NW;
+  const int lane = lane_id(), w = (int)threadIdx.y, tid = w * 64 + lane;
+  const int nroots = L.n_roots;
+  const float hX = L.hX;
+  // flatten into B: candidate order = cell-row-major, then (y, x) inside a cell
+  for (int i = tid; i < total; i += T) {
+    int lo = 0, hi = nc;  // largest c with cellpref[c] <= i
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (cellpref[mid] <= i) lo = mid; else hi = mid;
+    }
+    st.bufB[i] = candL[(size_t)lo * L.cand_cap_cell + (i - cellpref[lo])];
+  }
+  __syncthreads();
+  // B -> A grouped by root, order kept: root = int(x / hX) (extractor.cc:571-574)
+  team_prefix<NW>(total, ts.pref, ts.wtot, [&](int i) { return (int)__fdiv_rn((float)(st.bufB[i] & 0xFFF), hX); });
+  int rc[4], rbase[4], rpos[4];
+  {
+    const uint2 tot = ts.pref[total];
+    int acc = 0, np = 0;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      rc[rr] = rr < nroots ? pref_field(tot, rr) : 0;
+      rbase[rr] = acc;
+      rpos[rr] = np;
+      acc += rc[rr];
+      np += rc[rr] > 0 ? 1 : 0;
+    }
+  }
+  for (int i = tid; i < total; i += T) {
+    const uint32_t key = st.bufB[i];
+    const int r = (int)__fdiv_rn((float)(key & 0xFFF), hX);
+    const int pos = (r == 0 ? rbase[0] : r == 1 ? rbase[1] : r == 2 ? rbase[2] : rbase[3]) + pref_field(ts.pref[i], r);
+    st.bufA[pos] = key;
+    ts.ownCur[pos] = (unsigned short)(r == 0 ? rpos[0] : r == 1 ? rpos[1] : r == 2 ? rpos[2] : rpos[3]);
+  }
+  // root nodes (extractor.cc:558-586): empty ones are dropped
+  int n = 0;
+  {
+    const int hgt = L.h - 2 * ORBX_DET_ORG;  // maxBorderY - minBorderY
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      if (rc[rr] > 0) {
+        if (lane == 0) {
+          QNode nd;
+          nd.ulx = (short)(int)__fmul_rn(hX, (float)rr);
+          nd.brx = (short)(int)__fmul_rn(hX, (float)(rr + 1));
+          nd.uly = 0;
+          nd.bry = (short)hgt;
+          nd.start = rbase[rr];
+          nd.cnt = rc[rr];  // buffer A
+          st.cur[n] = nd;
+        }
+        ++n;
+      }
+    }
+  }
+  __syncthreads();
+
+  const int N = L.quota;
+  int nrec = 0;
+  bool finish = false, finalRounds = false;
+  // passes as in octree_level (extractor.cc:606-657, then :665-721)
+  while (!finish) {
+    const int prevSize = n;
+    int m = 0;
+    if (!finalRounds) {
+      for (int base = 0; base < n; base += 64) {
+        const int p = base + lane;
+        const bool exp = p < n && qcount(st.cur[p]) > 1;
+        const unsigned long long mask = __ballot(exp);
+        const int t = m + mbcnt64(mask);
+        if (exp) st.ord[t] = (unsigned short)p;
+        if (p < n) ts.tOf[p] = exp ? (short)t : (short)-1;
+        m += __popcll(mask);
+      }
+    } else {
+      if (w == 0)
+        oct_sort(rec, nrec, st.ord, (unsigned short*)st.cbase, (unsigned char*)st.newch,
+                 (orbx_sort::elem_t*)st.cnt4, (int*)st.nxt);
+      for (int p = tid; p < n; p += T) ts.tOf[p] = -1;
+      __syncthreads();
+      for (int t = tid; t < nrec; t += T) {
+        const unsigned short p = (unsigned short)(uint32_t)rec[nrec - 1 - t];
+        st.ord[t] = p;
+        ts.tOf[p] = (short)t;
+      }
+      m = nrec;
+    }
+    __syncthreads();
+    // keys per quadrant before every key, over the keys of the nodes to split
+    team_prefix<NW>(total, ts.pref, ts.wtot, [&](int i) {
+      const int p = ts.ownCur[i];
+      if (p == (int)OWN_NONE) return -1;
+      if (ts.tOf[p] < 0) return -1;
+      const QNode nd = st.cur[p];
+      const uint32_t key = (((unsigned)nd.cnt >> 31) ? st.bufB : st.bufA)[i];
+      return quadrant_of(key, nd.ulx + ((nd.brx - nd.ulx + 1) >> 1), nd.uly + ((nd.bry - nd.uly + 1) >> 1));
+    });
+    for (int t = tid; t < m; t += T) {
+      const QNode nd = st.cur[st.ord[t]];
+      const uint2 a = ts.pref[nd.start], b = ts.pref[nd.start + qcount(nd)];
+      const uint32_t dl = b.x - a.x, dh = b.y - a.y;
+      st.cnt4[t] = make_int4((int)(dl & 0xFFFFu), (int)(dl >> 16), (int)(dh & 0xFFFFu), (int)(dh >> 16));
+    }
+    __syncthreads();
+    int nch, nToExpand;
+    const int mEff = oct_place(st, m, n, N, finalRounds, &nch, &nToExpand);   // every wave for itself
+    wave_sync();
+    // every key of a node that is split moves to its child's range in the other buffer
+    for (int i = tid; i < total; i += T) {
+      const int p = ts.ownCur[i];
+      unsigned short nown = (unsigned short)OWN_NONE;
+      int pos = i;
+      if (p != (int)OWN_NONE) {
+        const int t = ts.tOf[p];
+        if (t >= 0 && t < mEff) {
+          const QNode nd = st.cur[p];
+          const int buf = (int)((unsigned)nd.cnt >> 31);
+          const uint32_t key = (buf ? st.bufB : st.bufA)[i];
+          const int q = quadrant_of(key, nd.ulx + ((nd.brx - nd.ulx + 1) >> 1), nd.uly + ((nd.bry - nd.uly + 1) >> 1));
+          const int4 c = st.cnt4[t];
+          const int off = q == 0 ? 0 : q == 1 ? c.x : q == 2 ? c.x + c.y : c.x + c.y + c.z;
+          pos = nd.start + off + pref_field(ts.pref[i], q) - pref_field(ts.pref[nd.start], q);
+          (buf ? st.bufA : st.bufB)[pos] = key;
+          const int child = st.cbase[t] + (q > 0 && c.x > 0) + (q > 1 && c.y > 0) + (q > 2 && c.z > 0);
+          nown = (unsigned short)(nch - 1 - child);   // the child's place in the rebuilt list
+        }
+      }
+      ts.ownNxt[pos] = nown;
+    }
+    __syncthreads();
+    for (int t = tid; t < mEff; t += T) {
+      const int p = st.ord[t];
+      const QNode nd = st.cur[p];
+      oct_write_children(st, nd, st.cnt4[t], st.cbase[t], nd.ulx + ((nd.brx - nd.ulx + 1) >> 1),
+                         nd.uly + ((nd.bry - nd.uly + 1) >> 1));
+      st.cur[p].cnt = 0;
+    }
+    __syncthreads();
+    n = rebuild_list(st.cur, n, st.newch, nch, st.nxt);   // every wave for itself, same records
+    nrec = build_records(st.newch, nch, rec);
+    { QNode* t = st.cur; st.cur = st.nxt; st.nxt = t; }
+    { unsigned short* t = ts.ownCur; ts.ownCur = ts.ownNxt; ts.ownNxt = t; }
+    __syncthreads();
+    if (n >= N || n == prevSize) finish = true;
+    else if (n + nToExpand * 3 > N) finalRounds = true;
+  }
+
+  // best key per node: highest score, first one wins ties (extractor.cc:726-742)
+  for (int p = tid; p < n; p += T) {
+    const QNode nd = st.cur[p];
+    const uint32_t* keys = (((unsigned)nd.cnt >> 31) ? st.bufB : st.bufA) + nd.start;
+    const int cnt = qcount(nd);
+    uint32_t best = keys[0];
+    for (int k = 1; k < cnt; ++k) {
+      const uint32_t kk = keys[k];
+      if ((kk >> 24) > (best >> 24)) best = kk;
+    }
+    if (p < L.sel_cap) out[p] = best;
+  }
+  if (tid == 0) *selCountSlot = n < L.sel_cap ? n : L.sel_cap;
+}
+
+// LDS of the team kernel: the node arrays and cell prefix of k_octree, then the team's own arrays
+// for plan->oct_team_keys keys.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_octree_team(const Plan* __restrict__ plan,
+                                                         const uint32_t* __restrict__ cand,
+                                                         const int* __restrict__ cellCount,
+                                                         uint32_t* __restrict__ flatA,
+                                                         uint32_t* __restrict__ flatB,
+                                                         uint32_t* __restrict__ sel,
+                                                         int* __restrict__ selCount, int f0, int l0) {
+  extern __shared__ __align__(16) uint8_t smemDyn[];
+  const int l = (int)blockIdx.y + l0, f = (int)blockIdx.x + f0;
+  const int lane = lane_id(), w = (int)threadIdx.y;
+  const LevelDesc& L = plan->lv[l];
+  const int cap = plan->oct_nodes_cap, tk = plan->oct_team_keys;
+  OctState st;
+  st.cnt4 = (int4*)smemDyn;                                    // 16-byte aligned first
+  st.cur = (QNode*)(st.cnt4 + cap);
+  st.nxt = st.cur + cap;
+  st.newch = st.nxt + cap;
+  orbx_sort::elem_t* rec = (orbx_sort::elem_t*)(st.newch + cap);
+  TeamState ts;
+  ts.pref = (uint2*)(rec + cap);
+  ts.wtot = ts.pref + (tk + 8);
+  uint32_t* ldsKeys = (uint32_t*)(ts.wtot + 2 * NW);
+  st.cbase = (int*)(ldsKeys + 2 * tk);
+  int* cellpref = st.cbase + cap;
+  st.ord = (unsigned short*)(cellpref + plan->oct_cells_max + 1);
+  ts.tOf = (short*)(st.ord + cap);
+  ts.ownCur = (unsigned short*)(ts.tOf + cap);
+  ts.ownNxt = ts.ownCur + tk;
+  __shared__ int rootCnt[ORBX_MAX_ROOTS];
+  __shared__ int waveTot[NW];
+
+  const int nc = L.ncx * L.ncy;
+  const int* cc = cellCount + (size_t)f * plan->cells_per_frame + L.cell_first;
+  // exclusive prefix of the cells' candidate counts: every wave scans its share, then the totals
+  int total = 0;
+  for (int base = 0; base < nc; base += 64 * NW) {
+    const int c = base + w * 64 + lane;
+    const int v = c < nc ? cc[c] : 0;
+    const int inc = wave_incl_scan(v);
+    if (lane == 63) waveTot[w] = inc;
+    __syncthreads();
+    int before = total;
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) {
+      const int t = waveTot[ww];
+      if (ww < w) before += t;
+      total += t;
+    }
+    if (c < nc) cellpref[c] = before + inc - v;
+    __syncthreads();
+  }
+  if (w == 0 && lane == 0) cellpref[nc] = total;
+  if (w == 0 && lane < ORBX_MAX_ROOTS) rootCnt[lane] = 0;
+  __syncthreads();
+  const uint32_t* candL = cand + (size_t)f * plan->cand_frame + L.cand_off;
+  uint32_t* out = sel + (size_t)f * plan->sel_frame + L.sel_off;
+  int* selCountSlot = selCount + (size_t)f * plan->nlevels + l;
+  if (total <= tk && L.n_roots <= 4) {
+    st.bufA = ldsKeys;
+    st.bufB = ldsKeys + tk;
+    team_octree_level<NW>(L, st, ts, rec, cellpref, candL, nc, total, out, selCountSlot);
+  } else if (w == 0) {
+    // more keys than the team's buffers hold (or more roots than its counters): wave 0 alone,
+    // keys in the global buffers
+    st.bufA = flatA + (size_t)f * plan->flat_frame + L.flat_off;
+    st.bufB = flatB + (size_t)f * plan->flat_frame + L.flat_off;
+    octree_level(plan, L, st, rec, cellpref, rootCnt, candL, nc, total, out, selCountSlot);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // K8: output slots.  One workgroup per frame.  Walks the selected keys in
 // (level, list order), scales coordinates, applies the lapping test and fills
 // the output from both ends exactly like extractor.cc:1052-1100.  Writes the
@@ -1445,13 +1753,11 @@ __global__ __launch_bounds__(256) void k_assemble(const Plan* __restrict__ plan,
   __shared__ int binCur[ORBX_MAX_LEVELS * 32];
   const int f = blockIdx.x + f0, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nl = plan->nlevels;
-  if (tid == 0) {
-    int acc = 0;
-    for (int l = 0; l < nl; ++l) {
-      lvOff[l] = acc;
-      acc += selCount[(size_t)f * nl + l];
-    }
-    lvOff[nl] = acc;
+  if (tid < 64) {   // the levels' counts in one round of loads (nl <= 64), then a wave scan
+    const int c = tid < nl ? selCount[(size_t)f * nl + tid] : 0;
+    const int inc = wave_incl_scan(c);
+    if (tid < nl) lvOff[tid] = inc - c;
+    if (tid == nl - 1) lvOff[nl] = inc;
   }
   __syncthreads();
   const int n = lvOff[nl];
@@ -2117,6 +2423,26 @@ __global__ __launch_bounds__(64) void k_orient_blur_describe(const Plan* __restr
 }
 
 // ---------------------------------------------------------------------------
+// Results of the first frame into page-locked host memory the GPU writes directly: the two counts,
+// then n keypoint records (7 words each) and n descriptors (8 words each).  One launch behind the
+// descriptor kernel instead of four copies handed to a copy engine.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_export_one(const int* __restrict__ d_n, const int* __restrict__ d_mono,
+                                                    const uint32_t* __restrict__ kps,
+                                                    const uint32_t* __restrict__ desc, int cap,
+                                                    int* __restrict__ hcnt, uint32_t* __restrict__ hk,
+                                                    uint32_t* __restrict__ hd) {
+  const int nAll = d_n[0];
+  if (blockIdx.x == 0 && threadIdx.x == 0) { hcnt[0] = nAll; hcnt[1] = d_mono[0]; }
+  const int n = nAll < cap ? nAll : cap;
+  const int nk = n * 7, nw = n * 15;
+  for (int i = (int)(blockIdx.x * 256 + threadIdx.x); i < nw; i += (int)gridDim.x * 256) {
+    if (i < nk) hk[i] = kps[i];
+    else hd[i - nk] = desc[i - nk];
+  }
+}
+
+// ---------------------------------------------------------------------------
 // launch functions (host): frames [f0, f0 + nframes) of the batch on stream s
 // ---------------------------------------------------------------------------
 void launch_pyramid(const Plan& hp, const uint8_t* d_img, int istride, size_t iframe, uint8_t* d_pyr,
@@ -2184,11 +2510,26 @@ size_t octree_lds_bytes(const Plan& hp) {
          (size_t)(hp.oct_cells_max + 1) * sizeof(int) + (size_t)hp.oct_keys_lds * 2 * sizeof(uint32_t) + 16;
 }
 
+constexpr int kOctTeamWaves = 4;
+
+size_t octree_team_lds_bytes(const Plan& hp) {
+  return (size_t)hp.oct_nodes_cap * (sizeof(int4) + 3 * sizeof(QNode) + sizeof(orbx_sort::elem_t) + sizeof(int) +
+                                      2 * sizeof(unsigned short)) +
+         (size_t)(hp.oct_team_keys + 8) * sizeof(uint2) + 2 * kOctTeamWaves * sizeof(uint2) +
+         (size_t)hp.oct_team_keys * (2 * sizeof(uint32_t) + 2 * sizeof(unsigned short)) +
+         (size_t)(hp.oct_cells_max + 1) * sizeof(int) + 16;
+}
+
 void launch_octree(const Plan& hp, const Plan* dp, const uint32_t* d_cand, const int* d_cellCount,
                    uint32_t* d_flatA, uint32_t* d_flatB, uint32_t* d_sel, int* d_selCount,
                    uint8_t* d_workspace, int l0, int l1, int f0, int nframes, hipStream_t s) {
   if (l1 <= l0) return;
   dim3 grid(nframes, l1 - l0);
+  if (hp.oct_team_keys > 0 && nframes <= hp.oct_team_frames) {
+    hipLaunchKernelGGL(k_octree_team<kOctTeamWaves>, grid, dim3(64, kOctTeamWaves), octree_team_lds_bytes(hp), s, dp,
+                       d_cand, d_cellCount, d_flatA, d_flatB, d_sel, d_selCount, f0, l0);
+    return;
+  }
   const size_t lds = hp.oct_ws_bytes ? 0 : octree_lds_bytes(hp);
   hipLaunchKernelGGL(hp.oct_ws_bytes ? k_octree<true> : k_octree<false>, grid, dim3(64), lds, s, dp, d_cand, d_cellCount,
                      d_flatA, d_flatB, d_sel, d_selCount, d_workspace, f0, l0);
@@ -2231,6 +2572,13 @@ void launch_describe_fused(const Plan& hp, const Plan* dp, const uint8_t* d_pyr,
                      f0, nblk, nunits, chunk);
 }
 
+void launch_export_one(const int* d_n, const int* d_mono, const float* d_kps, const uint8_t* d_desc, int cap,
+                       int* hcnt, void* hk, void* hd, hipStream_t s) {
+  const int blocks = cap * 15 / 1024 + 1;
+  hipLaunchKernelGGL(k_export_one, dim3(blocks < 64 ? blocks : 64), dim3(256), 0, s, d_n, d_mono, (const uint32_t*)d_kps,
+                     (const uint32_t*)d_desc, cap, hcnt, (uint32_t*)hk, (uint32_t*)hd);
+}
+
 int launch_debug_sort(uint64_t* d_data, int n, hipStream_t s) {
   const size_t lds = (size_t)n * 16 + 192 * 4 + (size_t)n * 4 + n + 32;
   if (lds > 64 * 1024 - 64) return -1;
@@ -2239,6 +2587,14 @@ int launch_debug_sort(uint64_t* d_data, int n, hipStream_t s) {
 }
 
 int octree_set_lds_limit(const Plan& hp) {
+  if (hp.oct_team_keys > 0) {
+    const size_t need = octree_team_lds_bytes(hp) + 256;
+    if (need > 160 * 1024) return -1;
+    if (need > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)k_octree_team<kOctTeamWaves>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)need) != hipSuccess)
+      return -1;
+  }
   if (hp.oct_ws_bytes) return 0;
   const size_t need = octree_lds_bytes(hp) + 256;
   if (need > 160 * 1024) return -1;

@@ -110,6 +110,8 @@ struct Plan {
   int oct_nodes_cap;     // quadtree node slots (max over levels)
   int oct_cells_max;     // max cells in one level
   int oct_keys_lds;      // keys per LDS key buffer of k_octree (0 = always use global memory)
+  int oct_team_keys;     // keys per LDS key buffer of k_octree_team (0 = kernel not used)
+  int oct_team_frames;   // batches of at most this many frames build their trees with k_octree_team
   uint32_t oct_ws_bytes; // 0: node arrays in LDS; else bytes of global workspace per (frame, level)
   int umax[16];          // circular patch row half-widths (extractor.cc:448-462)
   unsigned long long umax_packed;   // umax[v] in bits 4 v .. 4 v + 3

@@ -202,7 +202,8 @@ def test_device_resident_batch_matches_host_batch():
                                  {"ORBX_BLUR_PLANES": "1", "ORBX_SIDE_BLUR": "0"},
                                  {"ORBX_BLUR_PLANES": "1", "ORBX_SIDE_BLUR": "1"},
                                  {"ORBX_BLUR_PLANES": "1", "ORBX_SIDE_BLUR": "2"},
-                                 {"ORBX_FAST_SINGLE_PASS": "1"}, {"ORBX_OCT_KEYS_LDS": "0"}],
+                                 {"ORBX_FAST_SINGLE_PASS": "1"}, {"ORBX_OCT_KEYS_LDS": "0"}, {"ORBX_OCT_TEAM": "0"},
+                                 {"ORBX_OCT_TEAM": "0", "ORBX_OCT_KEYS_LDS": "0"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_timing_knobs_do_not_change_results(oracle, env, monkeypatch):
     """The environment knobs that exist for timing experiments (workgroup shapes and numbering, the
@@ -212,6 +213,27 @@ def test_timing_knobs_do_not_change_results(oracle, env, monkeypatch):
     for knob, value in env.items():
         monkeypatch.setenv(knob, value)
     compare_full(oracle, orbx.textured_frame(11, 640, 400), (600, 1.2, 6, 20, 7), (0, 1000))
+
+
+@pytest.mark.parametrize("team", ["0", "64"])
+@pytest.mark.parametrize("case", ["textured", "noise", "wide", "checker"])
+def test_quadtree_by_one_wave_and_by_a_team_of_waves(oracle, case, team, monkeypatch):
+    """Small batches build their quadtrees with a workgroup of four waves per (frame, level), large
+    ones with one wave; ORBX_OCT_TEAM=0 sends a single frame through the one-wave kernel.  Both
+    must equal the oracle: on a textured frame, on noise (more candidates on the big levels than the
+    team's LDS buffers hold: those levels are built by the team kernel's one-wave branch), on a
+    strip with seven quadtree roots (more than the team's four packed counters) and on a checkerboard
+    (every corner has the same score, so the result hangs on the order of the keys)."""
+    monkeypatch.setenv("ORBX_OCT_TEAM", team)
+    if case == "textured":
+        img, params = orbx.textured_frame(21, 752, 480), (1000, 1.2, 8, 20, 7)
+    elif case == "noise":
+        img, params = adversarial("noise", 752, 480), (1500, 1.2, 8, 20, 7)
+    elif case == "wide":
+        img, params = orbx.textured_frame(22, 1280, 220), (800, 1.2, 5, 20, 7)
+    else:
+        img, params = adversarial("checker", 640, 480), (700, 1.2, 8, 20, 7)
+    compare_full(oracle, img, params, (0, 1000))
 
 
 def test_detect_launch_history():

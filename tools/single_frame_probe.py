@@ -20,6 +20,26 @@ t0 = time.perf_counter()
 for _ in range(200):
     ex(img, None, (0, 1000))
 print("host call (python wrapper included): %.3f ms" % ((time.perf_counter() - t0) / 200 * 1e3))
+# the C entry point itself, image in ordinary and in page-locked memory
+import ctypes as C
+from orb_slam3_amd._lib import lib, check
+cap = ex.max_keypoints()
+k1 = np.zeros(cap * 28, np.uint8); d1 = np.zeros(cap * 32, np.uint8)
+n1, m1 = C.c_int32(), C.c_int32()
+pin = C.c_void_p()
+check(lib().orbx_host_alloc(W * H, C.byref(pin)), "orbx_host_alloc")
+C.memmove(pin, img.ctypes.data, W * H)
+for name, addr in (("ordinary", img.ctypes.data), ("page-locked", pin.value), ("ordinary", img.ctypes.data), ("page-locked", pin.value)):
+    def one():
+        check(lib().orbx_extract(ex._h, C.c_void_p(addr), W, H, W, 0, 1000, k1.ctypes.data_as(C.c_void_p),
+                                 d1.ctypes.data_as(C.c_void_p), cap, C.byref(n1), C.byref(m1)), "orbx_extract")
+    for _ in range(20):
+        one()
+    t0 = time.perf_counter()
+    for _ in range(300):
+        one()
+    print("orbx_extract, image in %s memory: %.3f ms (%d keypoints)" % (name, (time.perf_counter() - t0) / 300 * 1e3, n1.value))
+check(lib().orbx_host_free(pin), "orbx_host_free")
 ex.set_profiling(True)
 acc = {}
 for _ in range(50):
