@@ -310,12 +310,12 @@ def host_path_bench(torch, orbx, dev, local_rank, frames, n_frames=2048):
         check(lib().orbx_extract(ex1._h, C.c_void_p(img.ctypes.data), W, H, W, LAP[0], LAP[1],
                                  k1.ctypes.data_as(C.c_void_p), d1.ctypes.data_as(C.c_void_p), cap,
                                  C.byref(n1), C.byref(m1)), "orbx_extract")
-    for _ in range(5):
+    for _ in range(30):
         one()
     t0 = time.perf_counter()
-    for _ in range(50):
+    for _ in range(200):
         one()
-    out["single_frame_ms"] = (time.perf_counter() - t0) / 50 * 1e3
+    out["single_frame_ms"] = (time.perf_counter() - t0) / 200 * 1e3
     ex.close()
     ex1.close()
     return out

@@ -1437,8 +1437,8 @@ __global__ __launch_bounds__(64) void k_octree(const Plan* __restrict__ plan,
 // prefix minus the one at its node's start - the stable partition of every node of a pass in
 // one sweep.  own[] names the node (list position) that holds a key, OWN_NONE once that node
 // is final.  Steps that are short and serial by nature (the list of nodes to split, the
-// creation indices, the rebuilt list, the records) are executed by every wave on its own with
-// identical results; the sort of the final rounds runs on wave 0.
+// creation indices, the rebuilt list, the records, the sort of the final rounds) run on wave 0,
+// which hands their scalar results to the other waves through bc[].
 // Requires at most four roots and a key count within the LDS buffers; the caller falls back to
 // the one-wave form otherwise.
 // ---------------------------------------------------------------------------
@@ -1450,6 +1450,7 @@ struct TeamState {
   uint2* pref;              // per key position + 1: keys before it per class, (c0 | c1 << 16, c2 | c3 << 16)
   short* tOf;               // per list position: index in ord, -1 = not split in this pass
   uint2* wtot;              // 2 x NW wave totals of the scan
+  int* bc;                  // 8 words: scalar results of wave 0's steps
 };
 
 __device__ __forceinline__ int pref_field(uint2 v, int q) {
@@ -1541,7 +1542,7 @@ __device__ __forceinline__ void team_octree_level(const LevelDesc& L, OctState s
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
       if (rc[rr] > 0) {
-        if (lane == 0) {
+        if (tid == 0) {
           QNode nd;
           nd.ulx = (short)(int)__fmul_rn(hX, (float)rr);
           nd.brx = (short)(int)__fmul_rn(hX, (float)(rr + 1));
@@ -1565,14 +1566,17 @@ __device__ __forceinline__ void team_octree_level(const LevelDesc& L, OctState s
     const int prevSize = n;
     int m = 0;
     if (!finalRounds) {
-      for (int base = 0; base < n; base += 64) {
-        const int p = base + lane;
-        const bool exp = p < n && qcount(st.cur[p]) > 1;
-        const unsigned long long mask = __ballot(exp);
-        const int t = m + mbcnt64(mask);
-        if (exp) st.ord[t] = (unsigned short)p;
-        if (p < n) ts.tOf[p] = exp ? (short)t : (short)-1;
-        m += __popcll(mask);
+      if (w == 0) {
+        for (int base = 0; base < n; base += 64) {
+          const int p = base + lane;
+          const bool exp = p < n && qcount(st.cur[p]) > 1;
+          const unsigned long long mask = __ballot(exp);
+          const int t = m + mbcnt64(mask);
+          if (exp) st.ord[t] = (unsigned short)p;
+          if (p < n) ts.tOf[p] = exp ? (short)t : (short)-1;
+          m += __popcll(mask);
+        }
+        if (lane == 0) ts.bc[0] = m;
       }
     } else {
       if (w == 0)
@@ -1588,6 +1592,7 @@ __device__ __forceinline__ void team_octree_level(const LevelDesc& L, OctState s
       m = nrec;
     }
     __syncthreads();
+    if (!finalRounds) m = ts.bc[0];
     // keys per quadrant before every key, over the keys of the nodes to split
     team_prefix<NW>(total, ts.pref, ts.wtot, [&](int i) {
       const int p = ts.ownCur[i];
@@ -1604,9 +1609,13 @@ __device__ __forceinline__ void team_octree_level(const LevelDesc& L, OctState s
       st.cnt4[t] = make_int4((int)(dl & 0xFFFFu), (int)(dl >> 16), (int)(dh & 0xFFFFu), (int)(dh >> 16));
     }
     __syncthreads();
-    int nch, nToExpand;
-    const int mEff = oct_place(st, m, n, N, finalRounds, &nch, &nToExpand);   // every wave for itself
-    wave_sync();
+    if (w == 0) {
+      int nch0, nExp0;
+      const int mEff0 = oct_place(st, m, n, N, finalRounds, &nch0, &nExp0);
+      if (lane == 0) { ts.bc[1] = mEff0; ts.bc[2] = nch0; ts.bc[3] = nExp0; }
+    }
+    __syncthreads();
+    const int mEff = ts.bc[1], nch = ts.bc[2], nToExpand = ts.bc[3];
     // every key of a node that is split moves to its child's range in the other buffer
     for (int i = tid; i < total; i += T) {
       const int p = ts.ownCur[i];
@@ -1638,11 +1647,16 @@ __device__ __forceinline__ void team_octree_level(const LevelDesc& L, OctState s
       st.cur[p].cnt = 0;
     }
     __syncthreads();
-    n = rebuild_list(st.cur, n, st.newch, nch, st.nxt);   // every wave for itself, same records
-    nrec = build_records(st.newch, nch, rec);
+    if (w == 0) {
+      const int n0 = rebuild_list(st.cur, n, st.newch, nch, st.nxt);
+      const int nrec0 = build_records(st.newch, nch, rec);
+      if (lane == 0) { ts.bc[4] = n0; ts.bc[5] = nrec0; }
+    }
     { QNode* t = st.cur; st.cur = st.nxt; st.nxt = t; }
     { unsigned short* t = ts.ownCur; ts.ownCur = ts.ownNxt; ts.ownNxt = t; }
     __syncthreads();
+    n = ts.bc[4];
+    nrec = ts.bc[5];
     if (n >= N || n == prevSize) finish = true;
     else if (n + nToExpand * 3 > N) finalRounds = true;
   }
@@ -1695,6 +1709,8 @@ __global__ __launch_bounds__(64 * NW) void k_octree_team(const Plan* __restrict_
   ts.ownNxt = ts.ownCur + tk;
   __shared__ int rootCnt[ORBX_MAX_ROOTS];
   __shared__ int waveTot[NW];
+  __shared__ int teamVals[8];
+  ts.bc = teamVals;
 
   const int nc = L.ncx * L.ncy;
   const int* cc = cellCount + (size_t)f * plan->cells_per_frame + L.cell_first;

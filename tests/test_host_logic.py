@@ -98,7 +98,10 @@ def test_launch_block_sizes_match_launch_bounds():
               for m in re.finditer(r"__global__\s+__launch_bounds__\(([^)]*)\)\s+void\s+(\w+)", src)}
     assert not re.findall(r"__global__\s+void\s+\w+", src), "every kernel declares its launch bounds"
     # launches whose block size is a variable: checked where it is computed
-    by_variable = {"k_pyr_level0": "256", "kern": None}
+    # (k_octree_team<kOctTeamWaves> is launched with dim3(64, kOctTeamWaves) against bounds of 64 * NW:
+    # the same constant is the template argument and the block's second dimension)
+    by_variable = {"k_pyr_level0": "256", "kern": None, "k_octree_team": None}
+    assert re.search(r"k_octree_team<kOctTeamWaves>, grid, dim3\(64, kOctTeamWaves\)", src)
     seen = 0
     for m in re.finditer(r"hipLaunchKernelGGL\(\s*(?:orbx::)?(\w+)(?:<[^>]*>)?\s*,\s*(?:dim3\([^;]*?\)|[^,]+),"
                          r"\s*(?:dim3\(([^)]*)\)|([^,]+)),", src, re.S):
