@@ -168,6 +168,8 @@ int orbx_debug_level_blurred(orbx_extractor* ex, int frame, int level, uint8_t* 
  * std::sort(..., compareNodes) (extractor.cc:528-541, 673-674) including the order of
  * records with equal keys.  n <= 3000.  Test hook. */
 int orbx_debug_sort_records(int device_id, uint64_t* records, int n);
+/* The same with the sort of the multi-wave quadtree kernel that small batches use. */
+int orbx_debug_sort_records_team(int device_id, uint64_t* records, int n);
 
 /* ---- timing --------------------------------------------------------------- */
 #define ORBX_STAGE_PYRAMID 0

@@ -80,6 +80,7 @@ SIGNATURES = {
     "orbx_debug_level_selected": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, _i32p]),
     "orbx_debug_level_blurred": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "orbx_debug_sort_records": (C.c_int, [C.c_int, _P, C.c_int]),
+    "orbx_debug_sort_records_team": (C.c_int, [C.c_int, _P, C.c_int]),
     "orbx_set_profiling": (C.c_int, [_P, C.c_int]),
     "orbx_stage_times": (C.c_int, [_P, _f32p, C.c_int]),
     "orbx_detect_launch_times": (C.c_int, [_P, _f32p, _i32p, C.c_int, _i32p]),

@@ -64,7 +64,7 @@ void launch_frame_grid(const float* d_kps, const int* d_n, int cap, const orbx_p
 void launch_features_in_area(const float* d_kpsUn, int cap, const int* d_cellStart, const int* d_entries,
                              int frame, const float* bounds, const float* d_queries, int nq, int* d_out,
                              int percap, int* d_counts, hipStream_t s);
-int launch_debug_sort(uint64_t* d_data, int n, hipStream_t s);
+int launch_debug_sort(uint64_t* d_data, int n, int team, hipStream_t s);
 size_t projection_work_ints(int nLast, int n);
 size_t init_work_ints(int n1, int n2);
 void launch_search_by_projection_last(const uint8_t* d_lastValid, const float* d_uv, const float* d_invz,
@@ -2564,14 +2564,20 @@ int orbx_debug_level_blurred(orbx_extractor* ex, int frame, int level, uint8_t* 
   return ORBX_OK;
 }
 
-int orbx_debug_sort_records(int device_id, uint64_t* records, int n) {
+static int debug_sort(int device_id, uint64_t* records, int n, int team);
+
+int orbx_debug_sort_records(int device_id, uint64_t* records, int n) { return debug_sort(device_id, records, n, 0); }
+
+int orbx_debug_sort_records_team(int device_id, uint64_t* records, int n) { return debug_sort(device_id, records, n, 1); }
+
+static int debug_sort(int device_id, uint64_t* records, int n, int team) {
   if (!records || n < 0 || n > 3000) return ORBX_ERR_BAD_ARG;
   if (n == 0) return ORBX_OK;
   if (hipSetDevice(device_id) != hipSuccess) return ORBX_ERR_NO_DEVICE;
   uint64_t* d = nullptr;
   if (hipMalloc((void**)&d, (size_t)n * 8) != hipSuccess) return ORBX_ERR_HIP;
   hipError_t e = hipMemcpy(d, records, (size_t)n * 8, hipMemcpyHostToDevice);
-  if (e == hipSuccess && orbx::launch_debug_sort(d, n, nullptr) != 0) e = hipErrorInvalidValue;
+  if (e == hipSuccess && orbx::launch_debug_sort(d, n, team, nullptr) != 0) e = hipErrorInvalidValue;
   if (e == hipSuccess) e = hipGetLastError();
   if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e == hipSuccess) e = hipMemcpy(records, d, (size_t)n * 8, hipMemcpyDeviceToHost);

@@ -1102,13 +1102,105 @@ __device__ __forceinline__ int build_records(const QNode* newch, int nch, orbx_s
 // serial scan.  The closing insertion sort is stable and never moves an element across
 // a cut, i.e. it is a stable sort inside each final segment.  A segment whose depth
 // budget is spent is heap-sorted serially like the original (rare).
-// Scratch: posA/posB (n entries), segflag (n + 1 bytes), tmp (n elements), stk (3*64 ints).
-__device__ __forceinline__ void oct_sort(orbx_sort::elem_t* v, int n, unsigned short* posA, unsigned short* posB,
-                         unsigned char* segflag, orbx_sort::elem_t* tmp, int* stk) {
+// Scratch: posA/posB (n entries), segmask (n / 64 + 1 words of 64 bits), tmp (n elements), stk (3*64 ints).
+// words of list / stack scratch the sorts need for n records (oct_sort: 3 * 64; oct_sort_team: two
+// lists of n / 16 + 2 segments and their lengths)
+__host__ __device__ constexpr int debug_sort_stack_ints(int n, bool team) { return team ? 6 * (n / 16 + 2) + 2 : 192; }
+
+// One unguarded Hoare partition of [first, last) around the median of three, as std::sort does
+// it; returns the cut.  One wave; posA / posB: last - first entries each.
+__device__ __forceinline__ int oct_partition(orbx_sort::elem_t* v, int first, int last, unsigned short* posA,
+                                             unsigned short* posB) {
   using orbx_sort::less;
   const int lane = lane_id();
+  const int mid = first + (last - first) / 2;
+  if (lane == 0) orbx_sort::move_median_to_first(v, first, first + 1, mid, last - 1);
+  wave_sync();
+  const orbx_sort::elem_t P = v[first];
+  const int lo = first + 1, hi = last;
+  int nA = 0, nB = 0;
+  for (int base = lo; base < hi; base += 64) {
+    const int i = base + lane;
+    const bool fl = i < hi && !less(v[i], P);
+    const unsigned long long mask = __ballot(fl);
+    if (fl) posA[nA + mbcnt64(mask)] = (unsigned short)i;
+    nA += __popcll(mask);
+  }
+  for (int base = hi - 1; base >= lo; base -= 64) {
+    const int i = base - lane;
+    const bool fl = i >= lo && !less(P, v[i]);
+    const unsigned long long mask = __ballot(fl);
+    if (fl) posB[nB + mbcnt64(mask)] = (unsigned short)i;
+    nB += __popcll(mask);
+  }
+  wave_sync();
+  const int kmax = min(nA, nB);
+  int kstar = 0;
+  for (int base = 0; base < kmax; base += 64) {
+    const int k = base + lane;
+    const bool ok = k < kmax && posA[k] < posB[k];
+    const unsigned long long mask = __ballot(ok);
+    const int c = __popcll(mask);
+    kstar += c;
+    if (c < 64) break;
+  }
+  for (int k = lane; k < kstar; k += 64) {
+    const int a = posA[k], b = posB[k];
+    const orbx_sort::elem_t t = v[a];
+    v[a] = v[b];
+    v[b] = t;
+  }
+  const int ia = kstar < nA ? (int)posA[kstar] : 0x7fffffff;
+  const int ib = kstar > 0 ? (int)posB[kstar - 1] : 0x7fffffff;
+  return min(ia, ib);
+}
+
+// The closing pass: a stable sort inside every segment [s, e) between two cuts, by rank.  The
+// cuts are bits of segmask (bit i of word i / 64 = a segment starts at i; bits 0 and n are set).
+// `step` threads share the work, the caller's being number `me`.
+__device__ __forceinline__ void oct_sort_segments(const orbx_sort::elem_t* v, int n, const unsigned long long* segmask,
+                                                  orbx_sort::elem_t* tmp, int me, int step) {
+  using orbx_sort::less;
+  for (int i = me; i < n; i += step) {
+    int c = i >> 6;
+    const unsigned long long here = segmask[c];
+    const unsigned long long upto = here & (~0ull >> (63 - (i & 63)));   // bits <= i
+    const unsigned long long after = (i & 63) == 63 ? 0ull : here & (~0ull << ((i & 63) + 1));
+    int s0, e;
+    if (upto) s0 = (c << 6) + 63 - __clzll((long long)upto);
+    else {
+      int cc = c - 1;
+      unsigned long long m = segmask[cc];
+      while (!m) m = segmask[--cc];
+      s0 = (cc << 6) + 63 - __clzll((long long)m);
+    }
+    if (after) e = (c << 6) + __ffsll((long long)after) - 1;
+    else {
+      int cc = c + 1;
+      unsigned long long m = segmask[cc];
+      while (!m) m = segmask[++cc];
+      e = (cc << 6) + __ffsll((long long)m) - 1;
+    }
+    const orbx_sort::elem_t mine = v[i];
+    int rank = s0;
+    for (int j = s0; j < e; j += 4) {   // four loads in flight; the tail re-reads the last element
+      orbx_sort::elem_t o[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) o[u] = v[j + u < e ? j + u : e - 1];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        rank += (j + u < e && (less(o[u], mine) || (!less(mine, o[u]) && j + u < i))) ? 1 : 0;
+    }
+    tmp[rank] = mine;
+  }
+}
+
+__device__ __forceinline__ void oct_sort(orbx_sort::elem_t* v, int n, unsigned short* posA, unsigned short* posB,
+                         unsigned long long* segmask, orbx_sort::elem_t* tmp, int* stk) {
+  const int lane = lane_id();
   if (n <= 1) return;
-  for (int i = lane; i <= n; i += 64) segflag[i] = (i == 0 || i == n) ? 1 : 0;
+  for (int c = lane; c <= n >> 6; c += 64)
+    segmask[c] = (c == 0 ? 1ull : 0ull) | (c == n >> 6 ? 1ull << (n & 63) : 0ull);
   wave_sync();
   if (n > 16) {
     int sp = 0;
@@ -1126,49 +1218,10 @@ __device__ __forceinline__ void oct_sort(orbx_sort::elem_t* v, int n, unsigned s
           break;
         }
         --depth;
-        const int mid = first + (last - first) / 2;
-        if (lane == 0) orbx_sort::move_median_to_first(v, first, first + 1, mid, last - 1);
-        wave_sync();
-        const orbx_sort::elem_t P = v[first];
-        const int lo = first + 1, hi = last;
-        int nA = 0, nB = 0;
-        for (int base = lo; base < hi; base += 64) {
-          const int i = base + lane;
-          const bool fl = i < hi && !less(v[i], P);
-          const unsigned long long mask = __ballot(fl);
-          if (fl) posA[nA + mbcnt64(mask)] = (unsigned short)i;
-          nA += __popcll(mask);
-        }
-        for (int base = hi - 1; base >= lo; base -= 64) {
-          const int i = base - lane;
-          const bool fl = i >= lo && !less(P, v[i]);
-          const unsigned long long mask = __ballot(fl);
-          if (fl) posB[nB + mbcnt64(mask)] = (unsigned short)i;
-          nB += __popcll(mask);
-        }
-        wave_sync();
-        const int kmax = min(nA, nB);
-        int kstar = 0;
-        for (int base = 0; base < kmax; base += 64) {
-          const int k = base + lane;
-          const bool ok = k < kmax && posA[k] < posB[k];
-          const unsigned long long mask = __ballot(ok);
-          const int c = __popcll(mask);
-          kstar += c;
-          if (c < 64) break;
-        }
-        for (int k = lane; k < kstar; k += 64) {
-          const int a = posA[k], b = posB[k];
-          const orbx_sort::elem_t t = v[a];
-          v[a] = v[b];
-          v[b] = t;
-        }
-        const int ia = kstar < nA ? (int)posA[kstar] : 0x7fffffff;
-        const int ib = kstar > 0 ? (int)posB[kstar - 1] : 0x7fffffff;
-        const int cut = min(ia, ib);
+        const int cut = oct_partition(v, first, last, posA, posB);
         if (lane == 0) {
           stk[3 * sp] = cut; stk[3 * sp + 1] = last; stk[3 * sp + 2] = depth;
-          segflag[cut] = 1;
+          segmask[cut >> 6] |= 1ull << (cut & 63);
         }
         ++sp;
         last = cut;
@@ -1176,41 +1229,93 @@ __device__ __forceinline__ void oct_sort(orbx_sort::elem_t* v, int n, unsigned s
       }
     }
   }
-  // stable sort inside every segment [s, e)
-  for (int base = 0; base < n; base += 64) {
-    const int i = base + lane;
-    if (i < n) {
-      int s0 = i;
-      while (!segflag[s0]) --s0;
-      int e = i + 1;
-      while (!segflag[e]) ++e;
-      const orbx_sort::elem_t me = v[i];
-      int rank = s0;
-      for (int j = s0; j < e; ++j) {
-        const orbx_sort::elem_t o = v[j];
-        rank += (less(o, me) || (!less(me, o) && j < i)) ? 1 : 0;
-      }
-      tmp[rank] = me;
-    }
-  }
+  oct_sort_segments(v, n, segmask, tmp, lane, 64);
   wave_sync();
   for (int i = lane; i < n; i += 64) v[i] = tmp[i];
   wave_sync();
 }
 
-// Test hook: sorts n records in LDS with oct_sort and returns them.
-__global__ __launch_bounds__(64) void k_debug_sort(orbx_sort::elem_t* data, int n) {
+// The same sort by a team of NW waves.  Segments of a partition tree are independent, so the
+// partitions are taken breadth first: a wave takes a segment of this round's list, keeps its left
+// part and appends the right part to the next round's list - about log2(n / 16) rounds of one
+// partition each instead of n / 16 partitions one after the other.  Which wave partitions a
+// segment, and in which order segments are taken, does not change the result.
+// seg: two lists of (first, last, depth) with n / 16 + 2 entries each, then the two list lengths.
+// posA / posB are indexed from a segment's first element, so waves working on different segments
+// use different entries.  All waves of the workgroup must call.
+template <int NW>
+__device__ __forceinline__ void oct_sort_team(orbx_sort::elem_t* v, int n, unsigned short* posA,
+                                              unsigned short* posB, unsigned long long* segmask,
+                                              orbx_sort::elem_t* tmp, int* seg) {
+  constexpr int T = 64 * NW;
+  const int lane = lane_id(), w = (int)threadIdx.y, tid = w * 64 + lane;
+  if (n <= 1) return;
+  for (int c = tid; c <= n >> 6; c += T)
+    segmask[c] = (c == 0 ? 1ull : 0ull) | (c == n >> 6 ? 1ull << (n & 63) : 0ull);
+  if (n > 16) {
+    const int lcap = n / 16 + 2;
+    int* len = seg + 6 * lcap;
+    if (tid == 0) {
+      seg[0] = 0; seg[1] = n; seg[2] = 2 * orbx_sort::floor_log2(n);
+      len[0] = 1; len[1] = 0;
+    }
+    __syncthreads();
+    for (int cur = 0;; cur ^= 1) {
+      const int ncur = len[cur];
+      if (ncur == 0) break;
+      int* list = seg + 3 * lcap * cur;
+      int* next = seg + 3 * lcap * (cur ^ 1);
+      for (int sgi = w; sgi < ncur; sgi += NW) {
+        int first = list[3 * sgi], last = list[3 * sgi + 1], depth = list[3 * sgi + 2];
+        while (last - first > 16) {
+          if (depth == 0) {
+            if (lane == 0) orbx_sort::heap_sort_range(v, first, last);
+            wave_sync();
+            break;
+          }
+          --depth;
+          const int cut = oct_partition(v, first, last, posA + first, posB + first);
+          if (lane == 0) {
+            atomicOr(&segmask[cut >> 6], 1ull << (cut & 63));
+            if (last - cut > 16) {
+              const int at = atomicAdd(&len[cur ^ 1], 1);
+              next[3 * at] = cut; next[3 * at + 1] = last; next[3 * at + 2] = depth;
+            }
+          }
+          last = cut;
+          wave_sync();
+        }
+      }
+      __syncthreads();
+      if (tid == 0) len[cur] = 0;
+      __syncthreads();
+    }
+  } else {
+    __syncthreads();
+  }
+  oct_sort_segments(v, n, segmask, tmp, tid, T);
+  __syncthreads();
+  for (int i = tid; i < n; i += T) v[i] = tmp[i];
+  __syncthreads();
+}
+
+// Test hook: sorts n records in LDS with oct_sort (NW = 1) or oct_sort_team and returns them.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_debug_sort(orbx_sort::elem_t* data, int n) {
   extern __shared__ __align__(16) uint8_t smem[];
   orbx_sort::elem_t* v = (orbx_sort::elem_t*)smem;
   orbx_sort::elem_t* tmp = v + n;
-  int* stk = (int*)(tmp + n);
-  unsigned short* posA = (unsigned short*)(stk + 192);
+  unsigned long long* segmask = (unsigned long long*)(tmp + n);
+  int* stk = (int*)(segmask + (n >> 6) + 1);
+  unsigned short* posA = (unsigned short*)(stk + debug_sort_stack_ints(n, NW > 1));
   unsigned short* posB = posA + n;
-  unsigned char* segflag = (unsigned char*)(posB + n);
-  for (int i = threadIdx.x; i < n; i += 64) v[i] = data[i];
-  wave_sync();
-  oct_sort(v, n, posA, posB, segflag, tmp, stk);
-  for (int i = threadIdx.x; i < n; i += 64) data[i] = v[i];
+  const int tid = (int)(threadIdx.y * 64 + threadIdx.x);
+  for (int i = tid; i < n; i += 64 * NW) v[i] = data[i];
+  __syncthreads();
+  if constexpr (NW == 1) oct_sort(v, n, posA, posB, segmask, tmp, stk);
+  else oct_sort_team<NW>(v, n, posA, posB, segmask, tmp, stk);
+  __syncthreads();
+  for (int i = tid; i < n; i += 64 * NW) data[i] = v[i];
 }
 
 // The tree of one (frame, level) once its candidates are counted: `st` holds the node arrays and
@@ -1324,7 +1429,7 @@ __device__ __forceinline__ void octree_level(const Plan* __restrict__ plan, cons
         m += __popcll(mask);
       }
     } else {
-      oct_sort(rec, nrec, st.ord, (unsigned short*)st.cbase, (unsigned char*)st.newch,
+      oct_sort(rec, nrec, st.ord, (unsigned short*)st.cbase, (unsigned long long*)st.newch,
                (orbx_sort::elem_t*)st.cnt4, (int*)st.nxt);
       for (int t = lane; t < nrec; t += 64) st.ord[t] = (unsigned short)(uint32_t)rec[nrec - 1 - t];
       m = nrec;
@@ -1579,9 +1684,8 @@ __device__ __forceinline__ void team_octree_level(const LevelDesc& L, OctState s
         if (lane == 0) ts.bc[0] = m;
       }
     } else {
-      if (w == 0)
-        oct_sort(rec, nrec, st.ord, (unsigned short*)st.cbase, (unsigned char*)st.newch,
-                 (orbx_sort::elem_t*)st.cnt4, (int*)st.nxt);
+      oct_sort_team<NW>(rec, nrec, st.ord, (unsigned short*)st.cbase, (unsigned long long*)st.newch,
+                        (orbx_sort::elem_t*)st.cnt4, (int*)st.nxt);
       for (int p = tid; p < n; p += T) ts.tOf[p] = -1;
       __syncthreads();
       for (int t = tid; t < nrec; t += T) {
@@ -2595,10 +2699,17 @@ void launch_export_one(const int* d_n, const int* d_mono, const float* d_kps, co
                      (const uint32_t*)d_desc, cap, hcnt, (uint32_t*)hk, (uint32_t*)hd);
 }
 
-int launch_debug_sort(uint64_t* d_data, int n, hipStream_t s) {
-  const size_t lds = (size_t)n * 16 + 192 * 4 + (size_t)n * 4 + n + 32;
-  if (lds > 64 * 1024 - 64) return -1;
-  hipLaunchKernelGGL(k_debug_sort, dim3(1), dim3(64), lds, s, (orbx_sort::elem_t*)d_data, n);
+int launch_debug_sort(uint64_t* d_data, int n, int team, hipStream_t s) {
+  const size_t lds = (size_t)n * 16 + (size_t)debug_sort_stack_ints(n, team != 0) * 4 + (size_t)n * 4 + (size_t)(n / 64 + 1) * 8 + 32;
+  if (lds > 96 * 1024) return -1;
+  if (lds > 64 * 1024 - 64 &&
+      hipFuncSetAttribute(team ? (const void*)k_debug_sort<kOctTeamWaves> : (const void*)k_debug_sort<1>,
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return -1;
+  if (team)
+    hipLaunchKernelGGL(k_debug_sort<kOctTeamWaves>, dim3(1), dim3(64, kOctTeamWaves), lds, s, (orbx_sort::elem_t*)d_data, n);
+  else
+    hipLaunchKernelGGL(k_debug_sort<1>, dim3(1), dim3(64, 1), lds, s, (orbx_sort::elem_t*)d_data, n);
   return 0;
 }
 

@@ -125,8 +125,10 @@ def test_errors():
     assert e.value.status == -2
 
 
-def test_device_sort_matches_std_sort(oracle):
-    """The quadtree kernel's wave-parallel sort must give std::sort's permutation, ties included."""
+@pytest.mark.parametrize("entry", ["orbx_debug_sort_records", "orbx_debug_sort_records_team"])
+def test_device_sort_matches_std_sort(oracle, entry):
+    """The quadtree kernels' sorts (one wave; a team of waves taking the partitions breadth first)
+    must give std::sort's permutation, ties included."""
     import ctypes as C
     from orb_slam3_amd._lib import lib, check, ptr
     rng = np.random.default_rng(17)
@@ -148,7 +150,7 @@ def test_device_sort_matches_std_sort(oracle):
         perm_ref = oracle.sort_sized_nodes(size, ulx)
         rec = ((size.astype(np.uint64) << np.uint64(12) | ulx.astype(np.uint64)) << np.uint64(32)) | np.arange(n, dtype=np.uint64)
         rec = np.ascontiguousarray(rec)
-        check(lib().orbx_debug_sort_records(0, ptr(rec), n))
+        check(getattr(lib(), entry)(0, ptr(rec), n))
         perm = (rec & np.uint64(0xFFFFFFFF)).astype(np.int32)
         assert np.array_equal(perm, perm_ref), (n, size[:8], ulx[:8])
 

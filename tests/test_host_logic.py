@@ -100,7 +100,10 @@ def test_launch_block_sizes_match_launch_bounds():
     # launches whose block size is a variable: checked where it is computed
     # (k_octree_team<kOctTeamWaves> is launched with dim3(64, kOctTeamWaves) against bounds of 64 * NW:
     # the same constant is the template argument and the block's second dimension)
-    by_variable = {"k_pyr_level0": "256", "kern": None, "k_octree_team": None}
+    # (k_debug_sort<NW> likewise: dim3(64, kOctTeamWaves) or dim3(64, 1) against 64 * NW)
+    by_variable = {"k_pyr_level0": "256", "kern": None, "k_octree_team": None, "k_debug_sort": None}
+    assert re.search(r"k_debug_sort<kOctTeamWaves>, dim3\(1\), dim3\(64, kOctTeamWaves\)", src)
+    assert re.search(r"k_debug_sort<1>, dim3\(1\), dim3\(64, 1\)", src)
     assert re.search(r"k_octree_team<kOctTeamWaves>, grid, dim3\(64, kOctTeamWaves\)", src)
     seen = 0
     for m in re.finditer(r"hipLaunchKernelGGL\(\s*(?:orbx::)?(\w+)(?:<[^>]*>)?\s*,\s*(?:dim3\([^;]*?\)|[^,]+),"
