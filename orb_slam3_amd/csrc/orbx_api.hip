@@ -21,8 +21,8 @@
 #include "orbx_bow.h"
 
 namespace orbx {
-void launch_export_one(const int* d_n, const int* d_mono, const float* d_kps, const uint8_t* d_desc, int cap,
-                       int* hcnt, void* hk, void* hd, hipStream_t s);
+void launch_export_few(const int* d_n, const int* d_mono, const float* d_kps, const uint8_t* d_desc, int nframes,
+                       int kc, int cap, int G, int* hcnt, void* hk, void* hd, hipStream_t s);
 void launch_pyramid(const Plan& hp, const uint8_t* d_img, int istride, size_t iframe, uint8_t* d_pyr,
                     int f0, int nframes, hipStream_t s);
 void launch_knn2_frames(const uint8_t* descL, int capL, const int* nL, const int* monoL, const uint8_t* descR,
@@ -1222,59 +1222,72 @@ bool is_pinned_host(const void* p, size_t bytes) {
 }
 }  // namespace
 
-// One frame from host memory, the call Frame::ExtractORB makes (core/src/Frame.cc:461-470): no
-// groups, no helper streams, no packing threads and no copy engines - the image is packed into the
-// handle's page-locked buffer, which the first pyramid kernel reads over the bus; a last small
-// kernel writes the counts and the n records into page-locked memory; one synchronisation.
+// A few frames from host memory - one is the call Frame::ExtractORB makes
+// (core/src/Frame.cc:461-470), two a stereo pair, four a rig: no groups, no helper streams, no
+// packing threads and no copy engines.  The images are packed into the handle's page-locked
+// buffer, which the first pyramid kernel reads over the bus; a last small kernel writes the counts
+// and every frame's n records into page-locked memory; one synchronisation.
 // (Asking the runtime whether the caller's image is page-locked costs ten times what packing a
-// frame of a few hundred KB costs, so only large frames ask, and those go through a copy.)
-static int extract_one(orbx_extractor* ex, const uint8_t* img, int width, int height, int stride, int lap0,
-                       int lap1, orbx_keypoint* kps, uint8_t* desc, int cap, int* n_out, int* mono_out) {
+// frame of a few hundred KB costs, so only a single large frame asks, and that one goes through a
+// copy.)  Returns kNotFew when the frames are too many or too large for this path.
+constexpr int kNotFew = 1;
+constexpr int kFewFrames = 8;
+
+static int extract_few(orbx_extractor* ex, int n_frames, const uint8_t* const* imgs, int width, int height,
+                       int stride, int lap0, int lap1, orbx_keypoint* kps, uint8_t* desc, int cap, int* n_out,
+                       int* mono_out) {
   auto& last_hip_error = ex->last_hip_error;
   hipStream_t s = ex->stream;
   const size_t frameBytes = (size_t)width * height;
   const size_t srcBytes = (size_t)stride * (height - 1) + width;
-  const int kc = ex->hp.kp_cap;
+  const int kc = ex->hp.kp_cap, G = ex->groupFrames;
+  const bool small = (size_t)n_frames * frameBytes <= ((size_t)4 << 20);
+  if (n_frames > kFewFrames || n_frames > G || (!small && n_frames > 1)) return kNotFew;
   const int ccap = std::min(cap, kc);
   const bool wantK = kps && ccap > 0, wantD = desc && ccap > 0;
-  const bool small = frameBytes <= ((size_t)2 << 20);
-  const bool pinnedIn = !small && is_pinned_host(img, srcBytes);
+  const bool pinnedIn = !small && is_pinned_host(imgs[0], srcBytes);
   int st = ex->ensureHostStaging(!pinnedIn, true);
   if (st != ORBX_OK) return st;
-  const uint8_t* src = img;
+  const uint8_t* src = imgs[0];
   int sstride = stride;
   if (!pinnedIn) {
-    uint8_t* hin = ex->h_in[0];
-    if (stride == width) std::memcpy(hin, img, frameBytes);
-    else for (int y = 0; y < height; ++y) std::memcpy(hin + (size_t)y * width, img + (size_t)y * stride, width);
-    src = hin;
+    for (int f = 0; f < n_frames; ++f) {
+      uint8_t* hin = ex->h_in[0] + (size_t)f * frameBytes;
+      const uint8_t* img = imgs[f];
+      if (stride == width) std::memcpy(hin, img, frameBytes);
+      else for (int y = 0; y < height; ++y) std::memcpy(hin + (size_t)y * width, img + (size_t)y * stride, width);
+    }
+    src = ex->h_in[0];
     sstride = width;
   }
   void* srcDev = nullptr;
   if (small && hipHostGetDevicePointer(&srcDev, (void*)src, 0) == hipSuccess && srcDev) {
-    st = ex->run((const uint8_t*)srcDev, sstride, (size_t)sstride * height, 1, lap0, lap1);
+    st = ex->run((const uint8_t*)srcDev, width, frameBytes, n_frames, lap0, lap1);
   } else {
     (void)hipGetLastError();
-    if (sstride == width) HIP_TRY(hipMemcpyAsync(ex->d_img, src, frameBytes, hipMemcpyHostToDevice, s));
+    if (sstride == width) HIP_TRY(hipMemcpyAsync(ex->d_img, src, (size_t)n_frames * frameBytes, hipMemcpyHostToDevice, s));
     else HIP_TRY(hipMemcpy2DAsync(ex->d_img, width, src, sstride, width, height, hipMemcpyHostToDevice, s));
-    st = ex->run(ex->d_img, width, frameBytes, 1, lap0, lap1);
+    st = ex->run(ex->d_img, width, frameBytes, n_frames, lap0, lap1);
   }
   if (st != ORBX_OK) return st;
   int* hn = ex->h_cnt[0];
   uint8_t* hk = ex->h_out[0];
-  uint8_t* hd = hk + (size_t)ex->groupFrames * kc * 28;
-  orbx::launch_export_one(ex->d_n, ex->d_mono, ex->d_kps, ex->d_desc, ccap, hn, hk, hd, s);
+  uint8_t* hd = hk + (size_t)G * kc * 28;
+  orbx::launch_export_few(ex->d_n, ex->d_mono, ex->d_kps, ex->d_desc, n_frames, kc, ccap, G, hn, hk, hd, s);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(s));
-  const int n = hn[0];
-  if (n_out) *n_out = n;
-  if (mono_out) *mono_out = hn[1];
-  if (n > cap) return ORBX_ERR_CAPACITY;
-  if (n > 0) {
-    if (wantK) std::memcpy(kps, hk, (size_t)n * 28);
-    if (wantD) std::memcpy(desc, hd, (size_t)n * 32);
+  int worst = ORBX_OK;
+  for (int f = 0; f < n_frames; ++f) {
+    const int n = hn[f];
+    if (n_out) n_out[f] = n;
+    if (mono_out) mono_out[f] = hn[G + f];
+    if (n > cap) { worst = ORBX_ERR_CAPACITY; continue; }
+    if (n > 0) {
+      if (wantK) std::memcpy(kps + (size_t)f * cap, hk + (size_t)f * kc * 28, (size_t)n * 28);
+      if (wantD) std::memcpy(desc + (size_t)f * cap * 32, hd + (size_t)f * kc * 32, (size_t)n * 32);
+    }
   }
-  return ORBX_OK;
+  return worst;
 }
 
 int orbx_extract_batch(orbx_extractor* ex, int n_frames, const uint8_t* const* imgs, int width,
@@ -1289,7 +1302,10 @@ int orbx_extract_batch(orbx_extractor* ex, int n_frames, const uint8_t* const* i
   if (const int js_ = ex->joinParts()) return js_;
   int st = ex->ensurePlan(width, height);
   if (st != ORBX_OK) { ex->freePlan(); return st; }
-  if (n_frames == 1) return extract_one(ex, imgs[0], width, height, stride, lap0, lap1, kps, desc, cap, n_out, mono_out);
+  if (n_frames <= kFewFrames) {
+    st = extract_few(ex, n_frames, imgs, width, height, stride, lap0, lap1, kps, desc, cap, n_out, mono_out);
+    if (st != kNotFew) return st;
+  }
   auto& last_hip_error = ex->last_hip_error;
   const size_t frameBytes = (size_t)width * height;
   const size_t srcBytes = (size_t)stride * (height - 1) + width;

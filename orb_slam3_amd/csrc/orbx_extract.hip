@@ -2543,22 +2543,28 @@ __global__ __launch_bounds__(64) void k_orient_blur_describe(const Plan* __restr
 }
 
 // ---------------------------------------------------------------------------
-// Results of the first frame into page-locked host memory the GPU writes directly: the two counts,
-// then n keypoint records (7 words each) and n descriptors (8 words each).  One launch behind the
-// descriptor kernel instead of four copies handed to a copy engine.
+// Results of the first frames of a batch (one per blockIdx.y) into page-locked host memory the
+// GPU writes directly: the two counts (hcnt[f], hcnt[G + f]), then the frame's n keypoint records
+// (7 words each) and n descriptors (8 words each) at its slot of kc records.  One launch behind
+// the descriptor kernel instead of copies handed to a copy engine.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_export_one(const int* __restrict__ d_n, const int* __restrict__ d_mono,
+__global__ __launch_bounds__(256) void k_export_few(const int* __restrict__ d_n, const int* __restrict__ d_mono,
                                                     const uint32_t* __restrict__ kps,
-                                                    const uint32_t* __restrict__ desc, int cap,
+                                                    const uint32_t* __restrict__ desc, int kc, int cap, int G,
                                                     int* __restrict__ hcnt, uint32_t* __restrict__ hk,
                                                     uint32_t* __restrict__ hd) {
-  const int nAll = d_n[0];
-  if (blockIdx.x == 0 && threadIdx.x == 0) { hcnt[0] = nAll; hcnt[1] = d_mono[0]; }
+  const int f = (int)blockIdx.y;
+  const int nAll = d_n[f];
+  if (blockIdx.x == 0 && threadIdx.x == 0) { hcnt[f] = nAll; hcnt[G + f] = d_mono[f]; }
   const int n = nAll < cap ? nAll : cap;
   const int nk = n * 7, nw = n * 15;
+  const uint32_t* ksrc = kps + (size_t)f * kc * 7;
+  const uint32_t* dsrc = desc + (size_t)f * kc * 8;
+  uint32_t* kdst = hk + (size_t)f * kc * 7;
+  uint32_t* ddst = hd + (size_t)f * kc * 8;
   for (int i = (int)(blockIdx.x * 256 + threadIdx.x); i < nw; i += (int)gridDim.x * 256) {
-    if (i < nk) hk[i] = kps[i];
-    else hd[i - nk] = desc[i - nk];
+    if (i < nk) kdst[i] = ksrc[i];
+    else ddst[i - nk] = dsrc[i - nk];
   }
 }
 
@@ -2692,11 +2698,11 @@ void launch_describe_fused(const Plan& hp, const Plan* dp, const uint8_t* d_pyr,
                      f0, nblk, nunits, chunk);
 }
 
-void launch_export_one(const int* d_n, const int* d_mono, const float* d_kps, const uint8_t* d_desc, int cap,
-                       int* hcnt, void* hk, void* hd, hipStream_t s) {
+void launch_export_few(const int* d_n, const int* d_mono, const float* d_kps, const uint8_t* d_desc, int nframes,
+                       int kc, int cap, int G, int* hcnt, void* hk, void* hd, hipStream_t s) {
   const int blocks = cap * 15 / 1024 + 1;
-  hipLaunchKernelGGL(k_export_one, dim3(blocks < 64 ? blocks : 64), dim3(256), 0, s, d_n, d_mono, (const uint32_t*)d_kps,
-                     (const uint32_t*)d_desc, cap, hcnt, (uint32_t*)hk, (uint32_t*)hd);
+  hipLaunchKernelGGL(k_export_few, dim3(blocks < 64 ? blocks : 64, nframes), dim3(256), 0, s, d_n, d_mono,
+                     (const uint32_t*)d_kps, (const uint32_t*)d_desc, kc, cap, G, hcnt, (uint32_t*)hk, (uint32_t*)hd);
 }
 
 int launch_debug_sort(uint64_t* d_data, int n, int team, hipStream_t s) {

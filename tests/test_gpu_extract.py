@@ -409,6 +409,52 @@ def test_single_frame_host_call(oracle, pinned):
         lib().orbx_host_free(h)
 
 
+@pytest.mark.parametrize("B", [2, 3, 5, 8, 9])
+def test_host_call_with_a_few_frames(oracle, B):
+    """orbx_extract_batch with a handful of frames (a stereo pair, a rig) takes the path without
+    copy engines up to eight frames and the grouped path beyond; rows wider than the image, a
+    different image per frame, then a capacity that one frame exceeds: that frame reports its
+    count without data, the call returns ORBX_ERR_CAPACITY and the other frames are complete."""
+    import ctypes as C
+    from orb_slam3_amd._lib import lib, check, KEYPOINT_DTYPE, ORBX_ERR_CAPACITY
+    W, H, stride = 376, 240, 384
+    params = (300, 1.2, 5, 20, 7)
+    frames = [orbx.textured_frame(500 + i, W, H) for i in range(B)]
+    frames[1] = adversarial("noise", W, H)      # far more corners than the others
+    want, single = [], []
+    one = orbx.ORBextractor(*params)
+    for img in frames:
+        st, rmono, rk, rd = oracle.Extractor(*params).extract(img, (50, 300))
+        assert st == 0
+        want.append((rmono, rk, rd))
+        single.append(one(img, None, (50, 300)))     # angles and descriptor bits: the library's own single-frame result
+    wide = np.full((B, H, stride), 0x5A, np.uint8)
+    for f in range(B):
+        wide[f, :, :W] = frames[f]
+    ptrs = (C.c_void_p * B)(*[wide[f].ctypes.data for f in range(B)])
+    ex = orbx.ORBextractor(*params, max_batch=B)
+    i32p = C.POINTER(C.c_int32)
+    lens = [len(w[1]) for w in want]
+    for cap in (ex.max_keypoints(), max(lens) - 1):
+        kps = np.zeros((B, cap), KEYPOINT_DTYPE)
+        desc = np.zeros((B, cap, 32), np.uint8)
+        n = np.zeros(B, np.int32)
+        mono = np.zeros(B, np.int32)
+        status = lib().orbx_extract_batch(ex._h, B, ptrs, W, H, stride, 50, 300, kps.ctypes.data_as(C.c_void_p),
+                                          desc.ctypes.data_as(C.c_void_p), cap, n.ctypes.data_as(i32p),
+                                          mono.ctypes.data_as(i32p))
+        assert status == (ORBX_ERR_CAPACITY if cap < max(lens) else 0)
+        assert list(n) == lens and list(mono) == [w[0] for w in want]
+        for f in range(B):
+            if lens[f] > cap:
+                continue
+            for fld in ("x", "y", "size", "response", "octave", "class_id"):
+                assert np.array_equal(kps[fld][f, :lens[f]], want[f][1][fld]), (cap, f, fld)
+            assert np.array_equal(kps[f, :lens[f]], single[f][1]), (cap, f)
+            assert np.array_equal(desc[f, :lens[f]], single[f][2]), (cap, f)
+    ex.close()
+
+
 def test_two_part_batches_back_to_back(oracle):
     """Batches large enough to run as two parts on two streams, enqueued back to back without a
     synchronisation in between (the second part of one batch may still run while the first part of

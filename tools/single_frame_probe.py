@@ -35,10 +35,13 @@ for name, addr in (("ordinary", img.ctypes.data), ("page-locked", pin.value), ("
                                  d1.ctypes.data_as(C.c_void_p), cap, C.byref(n1), C.byref(m1)), "orbx_extract")
     for _ in range(20):
         one()
-    t0 = time.perf_counter()
+    per_call = []
     for _ in range(300):
+        t0 = time.perf_counter()
         one()
-    print("orbx_extract, image in %s memory: %.3f ms (%d keypoints)" % (name, (time.perf_counter() - t0) / 300 * 1e3, n1.value))
+        per_call.append(time.perf_counter() - t0)
+    print("orbx_extract, image in %s memory: median %.3f ms, mean %.3f ms, slowest call %.1f ms (%d keypoints)"
+          % (name, np.median(per_call) * 1e3, np.mean(per_call) * 1e3, max(per_call) * 1e3, n1.value))
 check(lib().orbx_host_free(pin), "orbx_host_free")
 ex.set_profiling(True)
 acc = {}

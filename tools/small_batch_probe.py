@@ -1,0 +1,35 @@
+"""Host-pointer calls with a few frames (a stereo pair, a rig of four cameras): time per call of
+orbx_extract_batch against the same frames resident on the device.
+Usage (GPU box): python tools/small_batch_probe.py"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ctypes as C
+import numpy as np, torch
+import orb_slam3_amd as orbx
+from orb_slam3_amd._lib import lib, check
+W, H = 752, 480
+frames = np.stack([orbx.textured_frame(100 + i, W, H) for i in range(8)])
+d = torch.from_numpy(frames).cuda()
+for B in (1, 2, 4, 8):
+    ex = orbx.ORBextractor(1000, 1.2, 8, 20, 7, device=0, max_batch=B)
+    cap = ex.max_keypoints()
+    ptrs = (C.c_void_p * B)(*[frames[i].ctypes.data for i in range(B)])
+    k = np.zeros((B, cap * 28), np.uint8); de = np.zeros((B, cap * 32), np.uint8)
+    n = np.zeros(B, np.int32); mono = np.zeros(B, np.int32)
+    i32p = C.POINTER(C.c_int32)
+    def host():
+        check(lib().orbx_extract_batch(ex._h, B, ptrs, W, H, W, 0, 1000, k.ctypes.data_as(C.c_void_p),
+                                       de.ctypes.data_as(C.c_void_p), cap, n.ctypes.data_as(i32p),
+                                       mono.ctypes.data_as(i32p)), "orbx_extract_batch")
+    def dev():
+        ex.extract_batch_device(d.data_ptr(), B, W, H, W, (0, 1000)); ex.sync()
+    out = []
+    for fn in (host, dev, host):
+        for _ in range(30):
+            fn()
+        t0 = time.perf_counter()
+        for _ in range(200):
+            fn()
+        out.append((time.perf_counter() - t0) / 200 * 1e3)
+    print("%d frames: host call %.3f ms (again after the device-resident loop: %.3f ms), device-resident chain %.3f ms"
+          % (B, out[0], out[2], out[1]), flush=True)
