@@ -21,6 +21,8 @@
 #include "orbx_bow.h"
 
 namespace orbx {
+void launch_copy_words2(const uint32_t* srcA, uint32_t* dstA, int nA, const uint32_t* srcB, uint32_t* dstB, int nB,
+                        hipStream_t s);
 void launch_export_few(const int* d_n, const int* d_mono, const float* d_kps, const uint8_t* d_desc, int nframes,
                        int kc, int cap, int G, int* hcnt, void* hk, void* hd, hipStream_t s);
 void launch_pyramid(const Plan& hp, const uint8_t* d_img, int istride, size_t iframe, uint8_t* d_pyr,
@@ -48,6 +50,8 @@ void launch_describe(const Plan& hp, const Plan* dp, const uint8_t* d_pyr, const
                      const WorkItem* d_work, const int* d_n, float* d_kps, uint8_t* d_desc,
                      int f0, int nframes, hipStream_t s);
 int octree_set_lds_limit(const Plan& hp);
+void launch_stereo_export_one(const int* nL, const float* uRight, const float* depth, int cap, int* hcnt, float* hu,
+                              float* hd, hipStream_t s);
 void launch_stereo(const Plan& hp, const Plan* dp, const uint8_t* pyrL, const uint8_t* pyrR,
                    const float* kpsL, const uint8_t* descL, const int* nL, int capL,
                    const float* kpsR, const uint8_t* descR, const int* nR, int capR, float mbf,
@@ -303,6 +307,9 @@ struct orbx_extractor {
   float* d_stDepth = nullptr;
   int stereoFrames = 0;
   // lapping-area 2-NN results of this (left) handle for a whole batch, allocated by the first call
+  uint8_t* d_lapOne = nullptr;     // records of one blocking orbx_lapping_knn2 call: [kp_cap] x (8 + 4) bytes
+  std::vector<int> hostN, hostMono;   // counts the last host-pointer extraction read back, per frame
+  int hostCountFrames = 0;            // frames for which they are valid (0 after a device-resident call)
   uint32_t* d_lapIdx = nullptr;    // [max_batch][kp_cap][2]
   uint16_t* d_lapDist = nullptr;
   int lapFrames = 0;
@@ -428,6 +435,8 @@ void orbx_extractor::freePlan() {
   for (void* b : sbufs) if (b) (void)hipFree(b);
   d_stRowStart = d_stEntries = nullptr; stRightCap = 0;
   d_stBandIdx = d_stBandDist = d_stSad = nullptr; d_stURight = d_stDepth = nullptr; stereoFrames = 0;
+  if (d_lapOne) (void)hipFree(d_lapOne);
+  d_lapOne = nullptr;
   if (d_lapIdx) (void)hipFree(d_lapIdx);
   if (d_lapDist) (void)hipFree(d_lapDist);
   if (d_lapCounts) (void)hipFree(d_lapCounts);
@@ -955,6 +964,7 @@ int orbx_extractor::enqueuePart(int pk, hipStream_t m, hipStream_t side, hipEven
 
 void orbx_extractor::afterExtraction(int nframes) {
   lastFrames = nframes;
+  hostCountFrames = 0;
   // results derived from the previous extraction (stereo association, frame grid, bag of words)
   // describe keypoints that no longer exist: their download / query calls fail until the
   // corresponding call has run again
@@ -1277,6 +1287,13 @@ static int extract_few(orbx_extractor* ex, int n_frames, const uint8_t* const* i
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(s));
   int worst = ORBX_OK;
+  try {
+    ex->hostN.assign(hn, hn + n_frames);
+    ex->hostMono.assign(hn + G, hn + G + n_frames);
+    ex->hostCountFrames = n_frames;
+  } catch (...) {
+    ex->hostCountFrames = 0;
+  }
   for (int f = 0; f < n_frames; ++f) {
     const int n = hn[f];
     if (n_out) n_out[f] = n;
@@ -1333,6 +1350,13 @@ int orbx_extract_batch(orbx_extractor* ex, int n_frames, const uint8_t* const* i
   HIP_TRY(hipStreamWaitEvent(ex->sIn, ex->evStart, 0));
 
   int worst = ORBX_OK;
+  bool countsKept = true;   // the counts read back below stay with the handle for later blocking calls
+  try {
+    ex->hostN.assign((size_t)n_frames, 0);
+    ex->hostMono.assign((size_t)n_frames, 0);
+  } catch (...) {
+    countsKept = false;
+  }
   // group k is done on the device and its results are where the caller wants them
   auto finish = [&](int k) -> int {
     const int b = k & 1, f0 = k * G, m = std::min(G, n_frames - f0);
@@ -1343,6 +1367,7 @@ int orbx_extract_batch(orbx_extractor* ex, int n_frames, const uint8_t* const* i
       if (n_out) n_out[f0 + i] = hn[i];
       if (mono_out) mono_out[f0 + i] = hm[i];
       if (hn[i] > cap) worst = ORBX_ERR_CAPACITY;
+      if (countsKept) { ex->hostN[f0 + i] = hn[i]; ex->hostMono[f0 + i] = hm[i]; }
     }
     if (stageOut) {
       const uint8_t* hk = ex->h_out[b];
@@ -1430,6 +1455,7 @@ int orbx_extract_batch(orbx_extractor* ex, int n_frames, const uint8_t* const* i
   ex->evValid = false;
   HIP_TRY(hipGetLastError());
   ex->afterExtraction(n_frames);
+  if (countsKept) ex->hostCountFrames = n_frames;
   return worst;
 }
 
@@ -1497,8 +1523,10 @@ int orbx_stereo_from_rgbd_batch_device(orbx_extractor* ex, int n_frames, const f
   return ORBX_OK;
 }
 
-int orbx_stereo_match_batch_device(orbx_extractor* left, orbx_extractor* right, int n_frames, float mbf,
-                                   float mb) {
+// `blocking`: the caller waits for the handle's stream before it returns, so the right handle needs
+// no order behind this work.
+static int stereo_enqueue(orbx_extractor* left, orbx_extractor* right, int n_frames, float mbf, float mb,
+                          bool blocking) {
   if (!left || !right || left == right || n_frames <= 0 || !(mb > 0.f) || !(mbf > 0.f))
     return ORBX_ERR_BAD_ARG;
   if (!same_geometry(left, right)) return ORBX_ERR_BAD_ARG;
@@ -1520,20 +1548,34 @@ int orbx_stereo_match_batch_device(orbx_extractor* left, orbx_extractor* right, 
     ex->stRightCap = right->hp.kp_cap;
   }
   if (!ex->evStereo) HIP_TRY(hipEventCreateWithFlags(&ex->evStereo, hipEventDisableTiming));
-  // the right extraction runs on its own stream: order this work after it
+  // the right extraction runs on its own stream: order this work after it (nothing to order when
+  // that stream has drained, as after a blocking extraction call)
   if (const int js_ = right->joinParts()) return js_;
-  HIP_TRY(hipEventRecord(ex->evStereo, right->stream));
-  HIP_TRY(hipStreamWaitEvent(ex->stream, ex->evStereo, 0));
+  const hipError_t busy = hipStreamQuery(right->stream);
+  if (busy == hipErrorNotReady) {
+    (void)hipGetLastError();
+    HIP_TRY(hipEventRecord(ex->evStereo, right->stream));
+    HIP_TRY(hipStreamWaitEvent(ex->stream, ex->evStereo, 0));
+  } else {
+    HIP_TRY(busy);
+  }
   orbx::launch_stereo(ex->hp, ex->dp, ex->d_pyr, right->d_pyr, ex->d_kps, ex->d_desc, ex->d_n,
                       ex->hp.kp_cap, right->d_kps, right->d_desc, right->d_n, right->hp.kp_cap, mbf, mb,
                       ex->d_stRowStart, ex->d_stEntries, ex->d_stBandIdx, ex->d_stBandDist, ex->d_stSad, ex->d_stURight, ex->d_stDepth,
                       n_frames, ex->stream);
   HIP_TRY(hipGetLastError());
   // the right handle's buffers must not be overwritten before this work has read them
-  HIP_TRY(hipEventRecord(ex->evStereo, ex->stream));
-  HIP_TRY(hipStreamWaitEvent(right->stream, ex->evStereo, 0));
+  if (!blocking) {
+    HIP_TRY(hipEventRecord(ex->evStereo, ex->stream));
+    HIP_TRY(hipStreamWaitEvent(right->stream, ex->evStereo, 0));
+  }
   ex->stereoFrames = n_frames;
   return ORBX_OK;
+}
+
+int orbx_stereo_match_batch_device(orbx_extractor* left, orbx_extractor* right, int n_frames, float mbf,
+                                   float mb) {
+  return stereo_enqueue(left, right, n_frames, mbf, mb, false);
 }
 
 int orbx_stereo_results_device(orbx_extractor* left, float** d_uright, float** d_depth, int* cap) {
@@ -1570,9 +1612,35 @@ int orbx_stereo_download(orbx_extractor* left, int frame, float* uright, float* 
 
 int orbx_stereo_match(orbx_extractor* left, orbx_extractor* right, float mbf, float mb, float* uright,
                       float* depth, int cap, int* n_out) {
-  int st = orbx_stereo_match_batch_device(left, right, 1, mbf, mb);
+  if (cap < 0) return ORBX_ERR_BAD_ARG;
+  int st = stereo_enqueue(left, right, 1, mbf, mb, true);
   if (st != ORBX_OK) return st;
-  return orbx_stereo_download(left, 0, uright, depth, nullptr, cap, n_out);
+  // count and results through page-locked memory the GPU writes, one wait (as in extract_few)
+  orbx_extractor* ex = left;
+  auto& last_hip_error = ex->last_hip_error;
+  const hipError_t queued = hipGetLastError();
+  st = ex->ensureHostStaging(false, true);
+  if (queued != hipSuccess || st != ORBX_OK) {
+    (void)hipStreamSynchronize(ex->stream);   // blocking promise: nothing of this call is left running
+    HIP_TRY(queued);
+    return st;
+  }
+  const int kc = ex->hp.kp_cap, ccap = std::min(cap, kc);
+  int* hn = ex->h_cnt[0];
+  float* hu = (float*)ex->h_out[0];
+  float* hdp = hu + kc;
+  orbx::launch_stereo_export_one(ex->d_n, ex->d_stURight, ex->d_stDepth, ccap, hn, hu, hdp, ex->stream);
+  const hipError_t launched = hipGetLastError();
+  HIP_TRY(hipStreamSynchronize(ex->stream));
+  HIP_TRY(launched);
+  const int n = hn[0];
+  if (n_out) *n_out = n;
+  if (n > cap) return ORBX_ERR_CAPACITY;
+  if (n > 0) {
+    if (uright) std::memcpy(uright, hu, (size_t)n * 4);
+    if (depth) std::memcpy(depth, hdp, (size_t)n * 4);
+  }
+  return ORBX_OK;
 }
 
 int orbx_lapping_knn2(orbx_extractor* left, orbx_extractor* right, int frame, uint32_t* idx, uint16_t* dist,
@@ -1586,16 +1654,29 @@ int orbx_lapping_knn2(orbx_extractor* left, orbx_extractor* right, int frame, ui
   auto& last_hip_error = ex->last_hip_error;
   hipStream_t s = ex->stream;
   if (!ex->evStereo) HIP_TRY(hipEventCreateWithFlags(&ex->evStereo, hipEventDisableTiming));
-  // the right extraction runs on its own stream: order this work after it
+  // the right extraction runs on its own stream: order this work after it (nothing to order when
+  // that stream has drained, as after a blocking extraction call)
   if (const int js_ = right->joinParts()) return js_;
-  HIP_TRY(hipEventRecord(ex->evStereo, right->stream));
-  HIP_TRY(hipStreamWaitEvent(s, ex->evStereo, 0));
+  const hipError_t busy = hipStreamQuery(right->stream);
+  if (busy == hipErrorNotReady) {
+    (void)hipGetLastError();
+    HIP_TRY(hipEventRecord(ex->evStereo, right->stream));
+    HIP_TRY(hipStreamWaitEvent(s, ex->evStereo, 0));
+  } else {
+    HIP_TRY(busy);
+  }
   int h[4] = {0, 0, 0, 0};   // Nleft, monoLeft, Nright, monoRight
-  HIP_TRY(hipMemcpyAsync(&h[0], left->d_n + frame, 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(&h[1], left->d_mono + frame, 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(&h[2], right->d_n + frame, 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(&h[3], right->d_mono + frame, 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
+  if (frame < left->hostCountFrames && frame < right->hostCountFrames) {
+    // both extractions came through host-pointer calls, which read these counts back
+    h[0] = left->hostN[frame]; h[1] = left->hostMono[frame];
+    h[2] = right->hostN[frame]; h[3] = right->hostMono[frame];
+  } else {
+    HIP_TRY(hipMemcpyAsync(&h[0], left->d_n + frame, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&h[1], left->d_mono + frame, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&h[2], right->d_n + frame, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&h[3], right->d_mono + frame, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
   const int nq = h[0] - h[1], nt = h[2] - h[3];
   if (n_query) *n_query = nq;
   if (mono_left) *mono_left = h[1];
@@ -1605,24 +1686,31 @@ int orbx_lapping_knn2(orbx_extractor* left, orbx_extractor* right, int frame, ui
   if (nq > cap) return ORBX_ERR_CAPACITY;
   if (nq == 0) return ORBX_OK;
   if (!idx || !dist) return ORBX_ERR_BAD_ARG;
-  uint8_t* d = nullptr;
-  const size_t oDist = ((size_t)nq * 8 + 255) / 256 * 256;
-  hipError_t e = hipMallocAsync((void**)&d, oDist + (size_t)nq * 4, s);
-  if (e != hipSuccess) { last_hip_error = e; return ORBX_ERR_HIP; }
+  if (nq > left->hp.kp_cap) return ORBX_ERR_BAD_ARG;
+  // records on the device, then through page-locked memory the GPU writes: one wait
+  const size_t oDist = (size_t)left->hp.kp_cap * 8;
+  if (!ex->d_lapOne) HIP_TRY(hipMalloc((void**)&ex->d_lapOne, (size_t)left->hp.kp_cap * 12));
+  int st = ex->ensureHostStaging(false, true);
+  if (st != ORBX_OK) return st;
+  uint8_t* d = ex->d_lapOne;
   const uint8_t* q = left->d_desc + ((size_t)frame * left->hp.kp_cap + h[1]) * 32;
   const uint8_t* t = right->d_desc + ((size_t)frame * right->hp.kp_cap + h[3]) * 32;
-  int st = orbx_knn2_device(q, nq, t, nt, 0, (uint32_t*)d, (uint16_t*)(d + oDist), (void*)s);
+  st = orbx_knn2_device(q, nq, t, nt, 0, (uint32_t*)d, (uint16_t*)(d + oDist), (void*)s);
+  hipError_t e = hipSuccess;
+  uint8_t* hb = ex->h_out[0];
   if (st == ORBX_OK) {
-    e = hipMemcpyAsync(idx, d, (size_t)nq * 8, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(dist, d + oDist, (size_t)nq * 4, hipMemcpyDeviceToHost, s);
+    orbx::launch_copy_words2((const uint32_t*)d, (uint32_t*)hb, 2 * nq, (const uint32_t*)(d + oDist),
+                             (uint32_t*)(hb + (size_t)nq * 8), nq, s);
+    e = hipGetLastError();
   }
   {
     const hipError_t es = hipStreamSynchronize(s);
     if (e == hipSuccess) e = es;
   }
-  (void)hipFreeAsync(d, s);
   if (st != ORBX_OK) return st;
   if (e != hipSuccess) { last_hip_error = e; return ORBX_ERR_HIP; }
+  std::memcpy(idx, hb, (size_t)nq * 8);
+  std::memcpy(dist, hb + (size_t)nq * 8, (size_t)nq * 4);
   return ORBX_OK;
 }
 

@@ -2698,6 +2698,23 @@ void launch_describe_fused(const Plan& hp, const Plan* dp, const uint8_t* d_pyr,
                      f0, nblk, nunits, chunk);
 }
 
+// Two word arrays to wherever the GPU can write (page-locked host memory: results of a blocking
+// call without a copy engine).
+__global__ __launch_bounds__(256) void k_copy_words2(const uint32_t* __restrict__ srcA, uint32_t* __restrict__ dstA,
+                                                     int nA, const uint32_t* __restrict__ srcB,
+                                                     uint32_t* __restrict__ dstB, int nB) {
+  for (int i = (int)(blockIdx.x * 256 + threadIdx.x); i < nA + nB; i += (int)gridDim.x * 256) {
+    if (i < nA) dstA[i] = srcA[i];
+    else dstB[i - nA] = srcB[i - nA];
+  }
+}
+
+void launch_copy_words2(const uint32_t* srcA, uint32_t* dstA, int nA, const uint32_t* srcB, uint32_t* dstB, int nB,
+                        hipStream_t s) {
+  const int blocks = (nA + nB) / 1024 + 1;
+  hipLaunchKernelGGL(k_copy_words2, dim3(blocks < 64 ? blocks : 64), dim3(256), 0, s, srcA, dstA, nA, srcB, dstB, nB);
+}
+
 void launch_export_few(const int* d_n, const int* d_mono, const float* d_kps, const uint8_t* d_desc, int nframes,
                        int kc, int cap, int G, int* hcnt, void* hk, void* hd, hipStream_t s) {
   const int blocks = cap * 15 / 1024 + 1;

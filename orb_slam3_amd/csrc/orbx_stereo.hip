@@ -267,6 +267,28 @@ int stereo_entries_per_keypoint(const Plan& hp) {
   return (int)(4.0f * hp.lv[hp.nlevels - 1].scale) + 3;
 }
 
+// The association's results for the first frame into page-locked host memory the GPU writes
+// directly: the keypoint count, then uRight and depth of the first min(n, cap) keypoints.
+__global__ __launch_bounds__(256) void k_stereo_export_one(const int* __restrict__ nL, const float* __restrict__ uRight,
+                                                           const float* __restrict__ depth, int cap,
+                                                           int* __restrict__ hcnt, float* __restrict__ hu,
+                                                           float* __restrict__ hd) {
+  const int nAll = nL[0];
+  if (blockIdx.x == 0 && threadIdx.x == 0) hcnt[0] = nAll;
+  const int n = nAll < cap ? nAll : cap;
+  for (int i = (int)(blockIdx.x * 256 + threadIdx.x); i < n; i += (int)gridDim.x * 256) {
+    hu[i] = uRight[i];
+    hd[i] = depth[i];
+  }
+}
+
+void launch_stereo_export_one(const int* nL, const float* uRight, const float* depth, int cap, int* hcnt, float* hu,
+                              float* hd, hipStream_t s) {
+  const int blocks = cap / 256 + 1;
+  hipLaunchKernelGGL(k_stereo_export_one, dim3(blocks < 16 ? blocks : 16), dim3(256), 0, s, nL, uRight, depth, cap, hcnt,
+                     hu, hd);
+}
+
 void launch_stereo(const Plan& hp, const Plan* dp, const uint8_t* pyrL, const uint8_t* pyrR,
                    const float* kpsL, const uint8_t* descL, const int* nL, int capL,
                    const float* kpsR, const uint8_t* descR, const int* nR, int capR, float mbf,

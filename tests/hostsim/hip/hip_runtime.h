@@ -91,6 +91,7 @@ hipError_t hipHostMalloc(void** p, size_t n, unsigned flags);
 hipError_t hipHostFree(void* p);
 hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* p);
 inline hipError_t hipHostGetDevicePointer(void** dev, void* host, unsigned) { *dev = host; return hipSuccess; }
+inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }   // launches run to completion before they return
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind k);
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t st);
 hipError_t hipMemcpy2D(void* d, size_t dpitch, const void* s, size_t spitch, size_t w, size_t h, hipMemcpyKind k);

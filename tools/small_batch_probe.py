@@ -33,3 +33,40 @@ for B in (1, 2, 4, 8):
         out.append((time.perf_counter() - t0) / 200 * 1e3)
     print("%d frames: host call %.3f ms (again after the device-resident loop: %.3f ms), device-resident chain %.3f ms"
           % (B, out[0], out[2], out[1]), flush=True)
+
+# one stereo frame the way Frame's stereo constructor makes it (core/src/Frame.cc:120-181):
+# left and right extraction on two handles, then ComputeStereoMatches
+from orb_slam3_amd import matcher
+L = orbx.textured_frame(300, W, H)
+R = np.roll(L, -12, axis=1)
+exl = orbx.ORBextractor(1200, 1.2, 8, 20, 7, device=0)
+exr = orbx.ORBextractor(1200, 1.2, 8, 20, 7, device=0)
+def frame():
+    exl(L, None, (0, 0)); exr(R, None, (0, 0))
+    return matcher.compute_stereo_matches(exl, exr, 47.9, 0.11)
+for part, fn in (("both extractions + association", frame),
+                 ("association alone", lambda: matcher.compute_stereo_matches(exl, exr, 47.9, 0.11))):
+    for _ in range(30):
+        fn()
+    per = []
+    for _ in range(200):
+        t0 = time.perf_counter(); fn(); per.append(time.perf_counter() - t0)
+    print("stereo frame, %s: median %.3f ms" % (part, np.median(per) * 1e3), flush=True)
+ur, dp = frame()
+print("matched %d of %d" % (int((ur >= 0).sum()), len(ur)))
+
+# one fisheye stereo frame (core/src/Frame.cc:1159-1177): two extractions with lapping areas, then
+# the 2-NN of the left lapping descriptors against the right ones, blocking
+exl = orbx.ORBextractor(1500, 1.2, 8, 20, 7, device=0)
+exr = orbx.ORBextractor(1500, 1.2, 8, 20, 7, device=0)
+Lf = orbx.textured_frame(400, 512, 512); Rf = orbx.textured_frame(401, 512, 512)
+def fisheye():
+    exl(Lf, None, (0, 511)); exr(Rf, None, (0, 511))
+    return matcher.lapping_knn_match2(exl, exr, 0)
+for part, fn in (("both extractions + 2-NN", fisheye), ("2-NN alone", lambda: matcher.lapping_knn_match2(exl, exr, 0))):
+    for _ in range(30):
+        fn()
+    per = []
+    for _ in range(200):
+        t0 = time.perf_counter(); fn(); per.append(time.perf_counter() - t0)
+    print("fisheye frame, %s: median %.3f ms" % (part, np.median(per) * 1e3), flush=True)
