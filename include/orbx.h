@@ -100,7 +100,11 @@ int orbx_pyramid(orbx_extractor* ex, int level, const uint8_t** padded, int* wid
  * copy engines directly - then entries of a frame beyond its n_out are
  * unspecified; ordinary memory goes through pinned staging filled by a few
  * host threads (up to 12, within OMP_NUM_THREADS and the machine's CPUs;
- * ORBX_HOST_THREADS overrides the number). */
+ * ORBX_HOST_THREADS overrides the number).  A call with at most eight frames
+ * and 4 MB of images (one frame, a stereo pair, a rig) is served for latency
+ * instead: no groups, helper streams or copy engines - the images are packed
+ * into page-locked memory the first kernel reads, the results are written
+ * to page-locked memory by a last small kernel, one wait. */
 int orbx_extract_batch(orbx_extractor* ex, int n_frames, const uint8_t* const* imgs, int width,
                        int height, int stride, int lap0, int lap1, orbx_keypoint* kps,
                        uint8_t* desc, int cap, int* n_out, int* mono_out);

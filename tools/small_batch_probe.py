@@ -27,12 +27,13 @@ for B in (1, 2, 4, 8):
     for fn in (host, dev, host):
         for _ in range(30):
             fn()
-        t0 = time.perf_counter()
+        per = []
         for _ in range(200):
-            fn()
-        out.append((time.perf_counter() - t0) / 200 * 1e3)
-    print("%d frames: host call %.3f ms (again after the device-resident loop: %.3f ms), device-resident chain %.3f ms"
-          % (B, out[0], out[2], out[1]), flush=True)
+            t0 = time.perf_counter(); fn(); per.append(time.perf_counter() - t0)
+        out.append((np.median(per) * 1e3, np.mean(per) * 1e3, max(per) * 1e3))
+    print("%d frames: host call median %.3f ms (mean %.3f, slowest %.2f; again after the device-resident loop: median %.3f, "
+          "mean %.3f, slowest %.2f), device-resident chain %.3f ms"
+          % (B, out[0][0], out[0][1], out[0][2], out[2][0], out[2][1], out[2][2], out[1][0]), flush=True)
 
 # one stereo frame the way Frame's stereo constructor makes it (core/src/Frame.cc:120-181):
 # left and right extraction on two handles, then ComputeStereoMatches
