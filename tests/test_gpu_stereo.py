@@ -138,3 +138,45 @@ def test_cv_adaptor_binary():
         __graft_entry__.build_adaptor_test()
     out = subprocess.run([exe], capture_output=True, text=True, timeout=100)
     assert out.returncode == 0 and out.stdout.startswith("ok"), out.stdout + out.stderr
+
+
+def test_left_and_right_extraction_from_two_threads(oracle):
+    """The stereo Frame constructor runs the two extractions on two threads
+    (core/src/Frame.cc:120-181: threadLeft / threadRight, then ComputeStereoMatches).  Two handles
+    called at the same time from two threads, many frames in a row, must give what the same
+    calls give one after the other, and the association that follows must equal the oracle's."""
+    import threading
+    from tests.conftest import HOSTSIM
+    if HOSTSIM:
+        pytest.skip("the kernel host simulation runs one launch at a time from one thread")
+    params = (1200, 1.2, 8, 20, 7)
+    lefts = [orbx.textured_frame(810 + i, 752, 480) for i in range(6)]
+    rights = [right_view(l, 810 + i) for i, l in enumerate(lefts)]
+    exl, exr = orbx.ORBextractor(*params), orbx.ORBextractor(*params)
+    serial = [(exl(l, None, (0, 0)), exr(r, None, (0, 0))) for l, r in zip(lefts, rights)]
+    failures = []
+
+    def work(ex, imgs, side, out):
+        try:
+            for rep in range(8):
+                for i, img in enumerate(imgs):
+                    mono, k, d = ex(img, None, (0, 0))
+                    ref = serial[i][side]
+                    if mono != ref[0] or not np.array_equal(k, ref[1]) or not np.array_equal(d, ref[2]):
+                        failures.append((side, rep, i))
+            out.append(True)
+        except Exception as e:   # noqa: BLE001 - reported by the assertion below
+            failures.append(repr(e))
+
+    done = []
+    threads = [threading.Thread(target=work, args=(exl, lefts, 0, done)),
+               threading.Thread(target=work, args=(exr, rights, 1, done))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not failures and len(done) == 2, failures[:5]
+    # both handles now hold the last pair
+    ur, dp = orbx.compute_stereo_matches(exl, exr, MBF, MB)
+    rur, rdp, _ = oracle_stereo(oracle, lefts[-1], rights[-1], params)
+    assert same_floats(ur, rur) and same_floats(dp, rdp)

@@ -55,6 +55,19 @@ for part, fn in (("both extractions + association", frame),
     print("stereo frame, %s: median %.3f ms" % (part, np.median(per) * 1e3), flush=True)
 ur, dp = frame()
 print("matched %d of %d" % (int((ur >= 0).sum()), len(ur)))
+# the same with the two extractions on two threads, as the reference's constructor runs them
+from concurrent.futures import ThreadPoolExecutor
+pool = ThreadPoolExecutor(2)
+def frame_threads():
+    a = pool.submit(exl, L, None, (0, 0)); b = pool.submit(exr, R, None, (0, 0))
+    a.result(); b.result()
+    return matcher.compute_stereo_matches(exl, exr, 47.9, 0.11)
+for _ in range(30):
+    frame_threads()
+per = []
+for _ in range(200):
+    t0 = time.perf_counter(); frame_threads(); per.append(time.perf_counter() - t0)
+print("stereo frame, extractions on two threads + association: median %.3f ms" % (np.median(per) * 1e3), flush=True)
 
 # one fisheye stereo frame (core/src/Frame.cc:1159-1177): two extractions with lapping areas, then
 # the 2-NN of the left lapping descriptors against the right ones, blocking
