@@ -300,6 +300,7 @@ def host_path_bench(torch, orbx, dev, local_rank, frames, n_frames=2048):
     pi[:] = src
     timed(pi, pin_k.numpy(), pin_d.numpy(), "pinned")
     # single-frame blocking call (the drop-in SLAM caller)
+    ex.close()
     ex1 = orbx.ORBextractor(*PARAMS, device=local_rank)
     k1 = np.zeros(cap, KEYPOINT_DTYPE)
     d1 = np.zeros((cap, 32), np.uint8)
@@ -322,7 +323,6 @@ def host_path_bench(torch, orbx, dev, local_rank, frames, n_frames=2048):
     # the library stays the same); the mean is kept beside it
     out["single_frame_ms"] = float(np.median(per_call)) * 1e3
     out["single_frame_ms_mean"] = float(np.mean(per_call)) * 1e3
-    ex.close()
     ex1.close()
     return out
 
