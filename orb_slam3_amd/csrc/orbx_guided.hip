@@ -100,6 +100,83 @@ __device__ __forceinline__ int hamming_reg(const uint32_t (&a)[8], const uint32_
   return d;
 }
 
+// ---- a window walked by a whole wave -------------------------------------------------------
+// One thread walking a window is a chain of dependent loads per keypoint (cell bounds -> entry ->
+// keypoint -> descriptor), a few hundred of them for the large windows of SearchForInitialization
+// or of a last-frame keypoint from a coarse level.  Here the 64 lanes of a wave share one window:
+// the cells of a grid column are consecutive in the cell table (c = column * 48 + row), so the
+// window is one contiguous run of entries per column; the lanes take the runs' entries in the
+// reference's order (column, row, order inside the cell), 64 at a time, and the accepted ones are
+// written to the query's candidate list in that order (ballot + prefix count).
+// colS / colP: 64 ints each, the calling wave's own.
+__device__ __forceinline__ void wave_mem_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <class Accept, class Encode>
+__device__ __forceinline__ void wave_gather_window(const GridView& g, float x, float y, float r, int minLevel,
+                                                   int maxLevel, const uint32_t* __restrict__ qdesc,
+                                                   const uint32_t* __restrict__ desc2, Accept accept, Encode encode,
+                                                   uint32_t* __restrict__ cand, size_t stride, int qi,
+                                                   int* __restrict__ countSlot, int* colS, int* colP) {
+  const int lane = (int)(threadIdx.x & 63u);
+  int k = 0;
+  // the cell range of Frame::GetFeaturesInArea, as in for_each_in_area
+  const int cx0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, g.minX), r), g.invW)));
+  const int cx1 = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, g.minX), r), g.invW)));
+  const int cy0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, g.minY), r), g.invH)));
+  const int cy1 = min(GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, g.minY), r), g.invH)));
+  if (cx0 < GRID_COLS && cx1 >= 0 && cy0 < GRID_ROWS && cy1 >= 0 && cx1 >= cx0 && cy1 >= cy0) {
+    const bool levelFilter = (minLevel > 0) || (maxLevel >= 0);
+    const int ncols = cx1 - cx0 + 1, ny = cy1 - cy0 + 1;
+    int first = 0, len = 0;
+    if (lane < ncols) {
+      const int c0 = (cx0 + lane) * GRID_ROWS + cy0;
+      first = g.cs[c0];
+      len = g.cs[c0 + ny] - first;
+    }
+    int inc = len;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(inc, d);
+      if (lane >= d) inc += o;
+    }
+    const int total = __shfl(inc, 63);
+    colS[lane] = first;
+    colP[lane] = inc - len;
+    wave_mem_sync();
+    uint32_t q[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) q[w] = qdesc[w];
+    for (int fb = 0; fb < total; fb += 64) {
+      const int f = fb + lane;
+      bool ok = f < total;
+      int i2 = 0, octave = 0, dist = 0;
+      if (ok) {
+        int lo = 0, hi = ncols;   // the last column whose run starts at or before f
+        while (hi - lo > 1) {
+          const int mid = (lo + hi) >> 1;
+          if (colP[mid] <= f) lo = mid; else hi = mid;
+        }
+        i2 = g.ent[colS[lo] + (f - colP[lo])];
+        const GKP kp = g.U[i2];
+        octave = kp.octave;
+        if (levelFilter && (kp.octave < minLevel || (maxLevel >= 0 && kp.octave > maxLevel))) ok = false;
+        const float distx = __fsub_rn(kp.x, x), disty = __fsub_rn(kp.y, y);
+        if (!(fabsf(distx) < r && fabsf(disty) < r)) ok = false;
+        if (ok && !accept(i2)) ok = false;
+        if (ok) dist = hamming_reg(q, desc2 + (size_t)i2 * 8);
+      }
+      const unsigned long long mask = __ballot(ok);
+      const int pos = k + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+      if (ok && pos < GUIDED_CACHE) cand[(size_t)pos * stride + qi] = encode(dist, octave, i2);
+      k += __popcll(mask);
+    }
+  }
+  if (lane == 0) *countSlot = k <= GUIDED_CACHE ? k : -1;
+}
+
 // rotation histogram bin as written at matcher.cc:694-700 / :1691-1699: the product with
 // 1/HISTO_LENGTH (not a division by the bin width), round() half away from zero
 __device__ __forceinline__ int rotation_bin(float angle1, float angle2) {
@@ -238,10 +315,39 @@ __device__ int projection_choice_cached(const ProjectionArgs& a, int i, const in
 // The window walks of all queries, spread over the chip: they do not depend on each other, and
 // one workgroup (one CU) would take them a few queries per thread, one dependent load after the
 // other.  The rounds kernel then starts from the remembered lists.
-#define GATHER_THREADS 64
+#define GATHER_THREADS 256
+#define GATHER_WAVES (GATHER_THREADS / 64)   /* one query per wave */
 __global__ __launch_bounds__(GATHER_THREADS) void k_gather_projection(ProjectionArgs a) {
-  const int i = blockIdx.x * GATHER_THREADS + threadIdx.x;
-  if (i < a.nLast) (void)projection_choice(a, i, nullptr, true, false);
+  __shared__ int colS[GATHER_WAVES][64], colP[GATHER_WAVES][64];
+  const int w = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
+  const int i = (int)blockIdx.x * GATHER_WAVES + w;
+  if (i >= a.nLast) return;
+  // the tests of projection_choice before its walk
+  bool walk = a.lastValid[i] != 0 && !(a.gate && a.gate[i] == 0);
+  const float invzc = walk ? a.invz[i] : 0.0f;
+  if (invzc < 0) walk = false;
+  const float u = walk ? a.uv[2 * i] : 0.0f, v = walk ? a.uv[2 * i + 1] : 0.0f;
+  if (walk && !a.skipBounds && (u < a.grid.minX || u > a.grid.maxX || v < a.grid.minY || v > a.grid.maxY)) walk = false;
+  if (!walk) {
+    if (lane == 0) a.candCount[i] = 0;
+    return;
+  }
+  const int nLastOctave = a.lastOctave[i];
+  const float radius = __fmul_rn(a.th, a.scale[nLastOctave]);
+  int minLevel, maxLevel;
+  if (a.forward) { minLevel = nLastOctave; maxLevel = -1; }
+  else if (a.backward) { minLevel = 0; maxLevel = nLastOctave; }
+  else { minLevel = nLastOctave - 1; maxLevel = nLastOctave + 1; }
+  const float ur = __fsub_rn(u, __fmul_rn(a.mbf, invzc));
+  wave_gather_window(
+      a.grid, u, v, radius, minLevel, maxLevel, a.lastDesc + (size_t)i * 8, a.desc,
+      [&](int i2) {
+        if (!a.uRight) return true;
+        const float r2 = a.uRight[i2];
+        return !(r2 > 0 && fabsf(__fsub_rn(ur, r2)) > radius);
+      },
+      [](int dist, int, int i2) { return ((uint32_t)dist << 16) | (uint32_t)i2; }, a.cand, (size_t)a.nLast, i,
+      &a.candCount[i], colS[w], colP[w]);
 }
 
 __global__ __launch_bounds__(GUIDED_THREADS) void k_search_by_projection_last(ProjectionArgs a) {
@@ -509,8 +615,30 @@ __device__ int points_choice_cached(const PointsArgs& a, int i, const int* close
 }
 
 __global__ __launch_bounds__(GATHER_THREADS) void k_gather_points(PointsArgs a) {
-  const int i = blockIdx.x * GATHER_THREADS + threadIdx.x;
-  if (i < a.nPts) (void)points_choice(a, i, nullptr, true, false);
+  __shared__ int colS[GATHER_WAVES][64], colP[GATHER_WAVES][64];
+  const int w = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
+  const int i = (int)blockIdx.x * GATHER_WAVES + w;
+  if (i >= a.nPts) return;
+  if (!a.inView[i]) {
+    if (lane == 0) a.candCount[i] = 0;
+    return;
+  }
+  // as points_walk
+  const int nPredictedLevel = a.level[i];
+  float r = (double)a.viewCos[i] > 0.998 ? 2.5f : 4.0f;
+  if ((double)a.th != 1.0) r = __fmul_rn(r, a.th);
+  const float radius = __fmul_rn(r, a.scale[nPredictedLevel]);
+  const float xr = a.uRight ? a.projXR[i] : 0.0f;
+  wave_gather_window(
+      a.grid, a.proj[2 * i], a.proj[2 * i + 1], radius, nPredictedLevel - 1, nPredictedLevel,
+      a.ptDesc + (size_t)i * 8, a.desc,
+      [&](int i2) {
+        if (!a.uRight) return true;
+        const float r2 = a.uRight[i2];
+        return !(r2 > 0 && fabsf(__fsub_rn(xr, r2)) > radius);
+      },
+      [](int dist, int octave, int i2) { return ((uint32_t)dist << 20) | ((uint32_t)octave << 16) | (uint32_t)i2; },
+      a.cand, (size_t)a.nPts, i, &a.candCount[i], colS[w], colP[w]);
 }
 
 __global__ __launch_bounds__(GUIDED_THREADS) void k_search_by_projection_points(PointsArgs a) {
@@ -755,9 +883,19 @@ __device__ void init_choice(const InitArgs& a, int i1, const int* claimDistPrev,
 }
 
 __global__ __launch_bounds__(GATHER_THREADS) void k_gather_init(InitArgs a) {
-  const int i = blockIdx.x * GATHER_THREADS + threadIdx.x;
-  int c, d;
-  if (i < a.n1) init_choice(a, i, nullptr, 3, &c, &d);
+  __shared__ int colS[GATHER_WAVES][64], colP[GATHER_WAVES][64];
+  const int w = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
+  const int i = (int)blockIdx.x * GATHER_WAVES + w;
+  if (i >= a.n1) return;
+  const int level1 = a.K1[i].octave;
+  if (level1 > 0) {   // matcher.cc:640-642: only keypoints of the finest level are searched
+    if (lane == 0) a.candCount[i] = 0;
+    return;
+  }
+  wave_gather_window(
+      a.grid, a.prevMatched[2 * i], a.prevMatched[2 * i + 1], a.window, level1, level1, a.desc1 + (size_t)i * 8,
+      a.desc2, [](int) { return true; }, [](int dist, int, int i2) { return ((uint32_t)dist << 16) | (uint32_t)i2; },
+      a.cand, (size_t)a.n1, i, &a.candCount[i], colS[w], colP[w]);
 }
 
 __global__ __launch_bounds__(GUIDED_THREADS) void k_search_for_initialization(InitArgs a) {
@@ -964,15 +1102,16 @@ static GridView make_grid(const float* d_kpsUn, const int* d_cellStart, const in
   return g;
 }
 
-// Whether the window walks get a launch of their own (ORBX_GUIDED_GATHER=0 / 1 forces it off /
-// on; results are the same either way).  With at most one query per thread of the rounds kernel
-// the walks already run side by side there, each a chain of dependent loads, and a second launch
-// would only add its own latency; it pays once threads would have to walk several queries in turn.
+// Whether the window walks get a launch of their own, one wave per query (ORBX_GUIDED_GATHER=0
+// leaves them to the threads of the rounds kernel, one query per thread and round trip after
+// round trip: the same results, several times the latency; kept as the path a query with more
+// candidates than its list holds takes anyway, and tested through the knob).
 static int gather_first(int nQueries) {
+  (void)nQueries;
   // (read at every call, so that a test can switch it inside one process)
   const char* e = getenv("ORBX_GUIDED_GATHER");
   if (e && e[0]) return atoi(e) != 0 ? 1 : 0;
-  return nQueries > GUIDED_THREADS ? 1 : 0;
+  return 1;
 }
 
 // work memory either launcher needs beyond its inputs and outputs, in ints
@@ -1003,7 +1142,7 @@ void launch_search_by_projection_last(const uint8_t* d_lastValid, const float* d
   a.gate = nullptr; a.skipBounds = 0; a.deferRotation = 0; a.finalChoice = nullptr;
   a.gathered = gather_first(nLast);
   if (a.gathered)
-    hipLaunchKernelGGL(k_gather_projection, dim3((nLast + GATHER_THREADS - 1) / GATHER_THREADS), dim3(GATHER_THREADS), 0,
+    hipLaunchKernelGGL(k_gather_projection, dim3((nLast + GATHER_WAVES - 1) / GATHER_WAVES), dim3(GATHER_THREADS), 0,
                        s, a);
   hipLaunchKernelGGL(k_search_by_projection_last, dim3(1), dim3(GUIDED_THREADS), 0, s, a);
 }
@@ -1051,7 +1190,7 @@ void launch_search_by_projection_last_rig(const uint8_t* d_lastValid, const floa
     a.skipBounds = cam;
     if (cam == 0) candCountL = a.candCount;
     if (a.gathered)
-      hipLaunchKernelGGL(k_gather_projection, dim3((nLast + GATHER_THREADS - 1) / GATHER_THREADS), dim3(GATHER_THREADS),
+      hipLaunchKernelGGL(k_gather_projection, dim3((nLast + GATHER_WAVES - 1) / GATHER_WAVES), dim3(GATHER_THREADS),
                          0, s, a);
     hipLaunchKernelGGL(k_search_by_projection_last, dim3(1), dim3(GUIDED_THREADS), 0, s, a);
   }
@@ -1089,7 +1228,7 @@ void launch_search_by_projection_points(const uint8_t* d_inView, const float* d_
   a.assigned = d_assigned; a.summary = d_summary;
   a.gathered = gather_first(nPts);
   if (a.gathered)
-    hipLaunchKernelGGL(k_gather_points, dim3((nPts + GATHER_THREADS - 1) / GATHER_THREADS), dim3(GATHER_THREADS), 0, s, a);
+    hipLaunchKernelGGL(k_gather_points, dim3((nPts + GATHER_WAVES - 1) / GATHER_WAVES), dim3(GATHER_THREADS), 0, s, a);
   hipLaunchKernelGGL(k_search_by_projection_points, dim3(1), dim3(GUIDED_THREADS), 0, s, a);
 }
 
@@ -1138,7 +1277,7 @@ void launch_search_by_projection_points_rig(const uint8_t* d_inView, const float
     a.choice[0][cam] = take(nPts);
     a.choice[1][cam] = take(nPts);
     a.head[cam] = take(p.n);
-    hipLaunchKernelGGL(k_gather_points, dim3((nPts + GATHER_THREADS - 1) / GATHER_THREADS), dim3(GATHER_THREADS), 0, s, p);
+    hipLaunchKernelGGL(k_gather_points, dim3((nPts + GATHER_WAVES - 1) / GATHER_WAVES), dim3(GATHER_THREADS), 0, s, p);
   }
   a.next = take(4 * (size_t)nPts);
   a.partner[0] = d_leftToRight; a.partner[1] = d_rightToLeft;
@@ -1186,7 +1325,7 @@ void launch_search_for_initialization(const float* d_kps1Un, const uint8_t* d_de
   a.matches12 = d_matches12; a.summary = d_summary;
   a.gathered = gather_first(n1);
   if (a.gathered)
-    hipLaunchKernelGGL(k_gather_init, dim3((n1 + GATHER_THREADS - 1) / GATHER_THREADS), dim3(GATHER_THREADS), 0, s, a);
+    hipLaunchKernelGGL(k_gather_init, dim3((n1 + GATHER_WAVES - 1) / GATHER_WAVES), dim3(GATHER_THREADS), 0, s, a);
   hipLaunchKernelGGL(k_search_for_initialization, dim3(1), dim3(GUIDED_THREADS), 0, s, a);
 }
 
