@@ -307,6 +307,8 @@ struct orbx_extractor {
   float* d_stDepth = nullptr;
   int stereoFrames = 0;
   // lapping-area 2-NN results of this (left) handle for a whole batch, allocated by the first call
+  uint8_t* d_guided = nullptr;     // inputs, work memory and results of one blocking guided-matcher call (grows)
+  size_t guidedBytes = 0;
   uint8_t* d_lapOne = nullptr;     // records of one blocking orbx_lapping_knn2 call: [kp_cap] x (8 + 4) bytes
   std::vector<int> hostN, hostMono;   // counts the last host-pointer extraction read back, per frame
   int hostCountFrames = 0;            // frames for which they are valid (0 after a device-resident call)
@@ -437,6 +439,8 @@ void orbx_extractor::freePlan() {
   d_stBandIdx = d_stBandDist = d_stSad = nullptr; d_stURight = d_stDepth = nullptr; stereoFrames = 0;
   if (d_lapOne) (void)hipFree(d_lapOne);
   d_lapOne = nullptr;
+  if (d_guided) (void)hipFree(d_guided);
+  d_guided = nullptr; guidedBytes = 0;
   if (d_lapIdx) (void)hipFree(d_lapIdx);
   if (d_lapDist) (void)hipFree(d_lapDist);
   if (d_lapCounts) (void)hipFree(d_lapCounts);
@@ -1959,6 +1963,78 @@ struct PackedUpload {
     return hipMemcpyAsync(d + lo, host.data() + lo, hi - lo, hipMemcpyHostToDevice, s);
   }
 };
+
+// One blocking guided-matcher call on a handle, the way the single-frame extraction is served:
+// the keypoint count from the last host-pointer extraction where that is the frame in question
+// (no first wait), one device block that stays with the handle, the host arrays packed into the
+// handle's page-locked buffer when they fit (else into ordinary memory), the results written to
+// page-locked memory by a kernel, one wait.
+struct GuidedCall {
+  orbx_extractor* ex;
+  hipStream_t s;
+  uint8_t* d = nullptr;        // device block
+  uint8_t* hup = nullptr;      // host block the arrays are packed into
+  bool pinnedUp = false;
+  PackedUpload pageable;
+  size_t lo = (size_t)-1, hi = 0;
+
+  int count(int frame, int* n) {
+    auto& last_hip_error = ex->last_hip_error;
+    if (frame < ex->hostCountFrames) { *n = ex->hostN[frame]; return ORBX_OK; }
+    HIP_TRY(hipMemcpyAsync(n, ex->d_n + frame, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return ORBX_OK;
+  }
+  int begin(size_t totalBytes, size_t uploadBytes) {
+    auto& last_hip_error = ex->last_hip_error;
+    if (totalBytes > ex->guidedBytes) {
+      HIP_TRY(hipStreamSynchronize(s));
+      if (ex->d_guided) HIP_TRY(hipFree(ex->d_guided));
+      ex->d_guided = nullptr; ex->guidedBytes = 0;
+      const size_t want = totalBytes + totalBytes / 4;
+      HIP_TRY(hipMalloc((void**)&ex->d_guided, want));
+      ex->guidedBytes = want;
+    }
+    d = ex->d_guided;
+    const int st = ex->ensureHostStaging(true, true);
+    if (st != ORBX_OK) return st;
+    if (uploadBytes <= (size_t)ex->groupFrames * ex->hp.W * ex->hp.H) {
+      hup = ex->h_in[0];
+      pinnedUp = true;
+    } else {
+      if (!pageable.init(uploadBytes)) return ORBX_ERR_UNSUPPORTED;
+      hup = pageable.host.data();
+    }
+    return ORBX_OK;
+  }
+  void add(size_t off, const void* src, size_t bytes) {
+    if (!bytes) return;
+    std::memcpy(hup + off, src, bytes);
+    lo = std::min(lo, off);
+    hi = std::max(hi, off + bytes);
+  }
+  hipError_t send() const {
+    if (hi <= lo) return hipSuccess;
+    return hipMemcpyAsync(d + lo, hup + lo, hi - lo, hipMemcpyHostToDevice, s);
+  }
+  // assigned[0, nn) and the two summary words to the host; waits for the stream (also when e
+  // already holds an error: the packed block must outlive whatever was enqueued)
+  hipError_t finish(hipError_t e, size_t oAsg, size_t nn, size_t oSum, int32_t* assigned, int* sum) {
+    uint8_t* hres = ex->h_out[0];
+    if (e == hipSuccess) {
+      orbx::launch_copy_words2((const uint32_t*)(d + oAsg), (uint32_t*)hres, (int)nn, (const uint32_t*)(d + oSum),
+                               (uint32_t*)(hres + nn * 4), 2, s);
+      e = hipGetLastError();
+    }
+    const hipError_t es = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = es;
+    if (e == hipSuccess) {
+      std::memcpy(assigned, hres, nn * 4);
+      std::memcpy(sum, hres + nn * 4, 8);
+    }
+    return e;
+  }
+};
 }  // namespace
 
 namespace {
@@ -1982,9 +2058,12 @@ int search_by_projection(orbx_extractor* cur, int frame, int n_last, const uint8
   if (const int js_ = ex->joinParts()) return js_;
   auto& last_hip_error = ex->last_hip_error;
   hipStream_t s = ex->stream;
+  GuidedCall call{ex, s};
   int n = 0;
-  HIP_TRY(hipMemcpyAsync(&n, ex->d_n + frame, 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
+  {
+    const int st = call.count(frame, &n);
+    if (st != ORBX_OK) return st;
+  }
   if (n_out) *n_out = n;
   *nmatches = 0;
   if (rounds) *rounds = 0;
@@ -2001,17 +2080,17 @@ int search_by_projection(orbx_extractor* cur, int frame, int n_last, const uint8
                oAng = c.add(nl * 4), oDesc = c.add(nl * 32), oObs = c.add(nl), oUr = c.add(nn * 4),
                oState = c.add(nn), oWork = c.add(orbx::projection_work_ints(n_last, n) * 4),
                oAsg = c.add(nn * 4), oSum = c.add(8);
-  uint8_t* d = nullptr;
-  hipError_t e = hipMallocAsync((void**)&d, c.total, s);
-  if (e != hipSuccess) { last_hip_error = e; return ORBX_ERR_HIP; }
-  PackedUpload pk;
-  if (!pk.init(oWork)) { (void)hipFreeAsync(d, s); return ORBX_ERR_UNSUPPORTED; }
-  auto up = [&](size_t off, const void* src, size_t bytes) { pk.add(off, src, bytes); };
+  {
+    const int st = call.begin(c.total, oWork);
+    if (st != ORBX_OK) return st;
+  }
+  uint8_t* d = call.d;
+  auto up = [&](size_t off, const void* src, size_t bytes) { call.add(off, src, bytes); };
   up(oValid, last_valid, nl); up(oUv, uv, nl * 8); up(oInvz, invz, nl * 4); up(oOct, last_octave, nl * 4);
   up(oAng, last_angle, nl * 4); up(oDesc, last_desc, nl * 32); up(oObs, last_obs, nl);
   if (u_right) up(oUr, u_right, nn * 4);
   if (state) up(oState, state, nn);
-  e = pk.send(d, s);
+  hipError_t e = call.send();
   int sum[2] = {0, 0};
   if (e == hipSuccess) {
     const size_t base = (size_t)frame * ex->hp.kp_cap;
@@ -2024,13 +2103,7 @@ int search_by_projection(orbx_extractor* cur, int frame, int n_last, const uint8
         (int*)(d + oWork), (int*)(d + oAsg), (int*)(d + oSum), s);
     e = hipGetLastError();
   }
-  if (e == hipSuccess) e = hipMemcpyAsync(assigned, d + oAsg, nn * 4, hipMemcpyDeviceToHost, s);
-  if (e == hipSuccess) e = hipMemcpyAsync(sum, d + oSum, 8, hipMemcpyDeviceToHost, s);
-  {   // also after an error: the packed host block must outlive whatever was enqueued
-    const hipError_t es = hipStreamSynchronize(s);
-    if (e == hipSuccess) e = es;
-  }
-  (void)hipFreeAsync(d, s);
+  e = call.finish(e, oAsg, nn, oSum, assigned, sum);
   if (e != hipSuccess) { last_hip_error = e; return ORBX_ERR_HIP; }
   *nmatches = sum[0];
   if (rounds) *rounds = sum[1];
@@ -2181,9 +2254,12 @@ int orbx_search_by_projection_points(orbx_extractor* f, int frame, int n_points,
   if (const int js_ = ex->joinParts()) return js_;
   auto& last_hip_error = ex->last_hip_error;
   hipStream_t s = ex->stream;
+  GuidedCall call{ex, s};
   int n = 0;
-  HIP_TRY(hipMemcpyAsync(&n, ex->d_n + frame, 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
+  {
+    const int st = call.count(frame, &n);
+    if (st != ORBX_OK) return st;
+  }
   if (n_out) *n_out = n;
   *nmatches = 0;
   if (rounds) *rounds = 0;
@@ -2200,17 +2276,17 @@ int orbx_search_by_projection_points(orbx_extractor* f, int frame, int n_points,
                oCos = c.add(np * 4), oDesc = c.add(np * 32), oObs = c.add(np), oUr = c.add(nn * 4),
                oState = c.add(nn), oWork = c.add(orbx::projection_work_ints(n_points, n) * 4),
                oAsg = c.add(nn * 4), oSum = c.add(8);
-  uint8_t* d = nullptr;
-  hipError_t e = hipMallocAsync((void**)&d, c.total, s);
-  if (e != hipSuccess) { last_hip_error = e; return ORBX_ERR_HIP; }
-  PackedUpload pk;
-  if (!pk.init(oWork)) { (void)hipFreeAsync(d, s); return ORBX_ERR_UNSUPPORTED; }
-  auto up = [&](size_t off, const void* src, size_t bytes) { pk.add(off, src, bytes); };
+  {
+    const int st = call.begin(c.total, oWork);
+    if (st != ORBX_OK) return st;
+  }
+  uint8_t* d = call.d;
+  auto up = [&](size_t off, const void* src, size_t bytes) { call.add(off, src, bytes); };
   up(oView, in_view, np); up(oProj, proj, np * 8); up(oXr, proj_xr, np * 4); up(oLvl, level, np * 4);
   up(oCos, view_cos, np * 4); up(oDesc, desc, np * 32); up(oObs, obs, np);
   if (u_right) up(oUr, u_right, nn * 4);
   if (state) up(oState, state, nn);
-  e = pk.send(d, s);
+  hipError_t e = call.send();
   int sum[2] = {0, 0};
   if (e == hipSuccess) {
     const size_t base = (size_t)frame * ex->hp.kp_cap;
@@ -2222,13 +2298,7 @@ int orbx_search_by_projection_points(orbx_extractor* f, int frame, int n_points,
         ex->scale.data(), ex->prm.nlevels, th, nnratio, (int*)(d + oWork), (int*)(d + oAsg), (int*)(d + oSum), s);
     e = hipGetLastError();
   }
-  if (e == hipSuccess) e = hipMemcpyAsync(assigned, d + oAsg, nn * 4, hipMemcpyDeviceToHost, s);
-  if (e == hipSuccess) e = hipMemcpyAsync(sum, d + oSum, 8, hipMemcpyDeviceToHost, s);
-  {   // also after an error: the packed host block must outlive whatever was enqueued
-    const hipError_t es = hipStreamSynchronize(s);
-    if (e == hipSuccess) e = es;
-  }
-  (void)hipFreeAsync(d, s);
+  e = call.finish(e, oAsg, nn, oSum, assigned, sum);
   if (e != hipSuccess) { last_hip_error = e; return ORBX_ERR_HIP; }
   *nmatches = sum[0];
   if (rounds) *rounds = sum[1];
