@@ -75,41 +75,54 @@ __global__ __launch_bounds__(BOW_THREADS) void k_bow_descend(VocDevice voc, cons
   }
 }
 
-// ascending bitonic sort of P (a power of two) 64-bit keys by the whole workgroup
-__device__ void block_sort(uint64_t* keys, int P) {
+// ascending bitonic sort of P (a power of two) 64-bit keys by the whole workgroup: one
+// compare-exchange pair per thread and trip.  A wave's 64 pairs of a trip lie in one aligned block
+// of 128 keys whenever the distance is at most 64, in every such step the same block: those steps
+// need the wave's program order only, not a workgroup barrier (51 of the 66 steps for 2048 keys).
+#define BOWA_THREADS 1024   /* k_bow_assemble: one pair per thread for 2048 keys */
+__device__ __forceinline__ void block_sort(uint64_t* keys, int P) {
+  const int half = P >> 1;
   for (int k = 2; k <= P; k <<= 1)
     for (int jj = k >> 1; jj > 0; jj >>= 1) {
-      for (int t = threadIdx.x; t < P; t += BOW_THREADS) {
-        const int o = t ^ jj;
-        if (o > t) {
-          const uint64_t x = keys[t], y = keys[o];
-          const bool up = (t & k) == 0;
-          if ((x > y) == up) { keys[t] = y; keys[o] = x; }
-        }
+      if (jj > 64) __syncthreads();
+      for (int i = threadIdx.x; i < half; i += BOWA_THREADS) {
+        const int t = ((i & ~(jj - 1)) << 1) | (i & (jj - 1)), o = t | jj;
+        const uint64_t x = keys[t], y = keys[o];
+        const bool up = (t & k) == 0;
+        if ((x > y) == up) { keys[t] = y; keys[o] = x; }
       }
-      __syncthreads();
+      if (jj > 64) {
+        __syncthreads();
+      } else {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
     }
+  __syncthreads();
 }
 
 // For sorted keys[0..m): run r = maximal range of equal high words.  Writes runStart[r] for
-// every run and runStart[R] = m; returns R.  (Block-wide; scratch = BOW_THREADS ints of LDS.)
-__device__ int block_runs(const uint64_t* keys, int m, int* runStart, int* scratch) {
-  const int tid = threadIdx.x;
+// every run and runStart[R] = m; returns R.  (Block-wide; scratch = one int of LDS per wave.)
+__device__ __forceinline__ int block_runs(const uint64_t* keys, int m, int* runStart, int* scratch) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NWAVES = BOWA_THREADS / 64;
   int base = 0;
-  for (int c0 = 0; c0 < m; c0 += BOW_THREADS) {
+  for (int c0 = 0; c0 < m; c0 += BOWA_THREADS) {
     const int t = c0 + tid;
-    const int head = (t < m && (t == 0 || (uint32_t)(keys[t] >> 32) != (uint32_t)(keys[t - 1] >> 32))) ? 1 : 0;
-    scratch[tid] = head;
+    const bool head = t < m && (t == 0 || (uint32_t)(keys[t] >> 32) != (uint32_t)(keys[t - 1] >> 32));
+    // a run's number = heads before it: inside the wave from the ballot, across waves from LDS
+    const unsigned long long mask = __ballot(head);
+    if (lane == 0) scratch[wave] = __popcll(mask);
     __syncthreads();
-    // inclusive scan of the 256 flags (Hillis-Steele, 8 steps)
-    for (int d = 1; d < BOW_THREADS; d <<= 1) {
-      const int v = tid >= d ? scratch[tid - d] : 0;
-      __syncthreads();
-      scratch[tid] += v;
-      __syncthreads();
+    int before = base, total = 0;
+#pragma unroll
+    for (int w = 0; w < NWAVES; ++w) {
+      const int c = scratch[w];
+      if (w < wave) before += c;
+      total += c;
     }
-    if (head) runStart[base + scratch[tid] - 1] = t;
-    const int total = scratch[BOW_THREADS - 1];
+    if (head)
+      runStart[before + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u))] = t;
     __syncthreads();
     base += total;
   }
@@ -118,7 +131,12 @@ __device__ int block_runs(const uint64_t* keys, int m, int* runStart, int* scrat
   return base;
 }
 
-__global__ __launch_bounds__(BOW_THREADS) void k_bow_assemble(const int* __restrict__ nP, int cap, int P,
+// KEYS_GLOBAL: the sort keys live in the caller's workspace (a frame with more keys than LDS
+// holds); else in LDS, and instantiated apart so that the sort's accesses are LDS instructions
+// rather than flat ones (a flat access to LDS takes the long way through the memory pipeline:
+// the kernel took 137 us per frame that way, most of it in the two sorts).
+template <bool KEYS_GLOBAL>
+__global__ __launch_bounds__(BOWA_THREADS) void k_bow_assemble(const int* __restrict__ nP, int cap, int P,
                                                               const uint32_t* __restrict__ featWord,
                                                               const double* __restrict__ featWeight,
                                                               const uint32_t* __restrict__ featNode,
@@ -128,31 +146,33 @@ __global__ __launch_bounds__(BOW_THREADS) void k_bow_assemble(const int* __restr
                                                               uint32_t* __restrict__ fvNode, int* __restrict__ fvStart,
                                                               uint32_t* __restrict__ fvFeat, int* __restrict__ fvCount) {
   extern __shared__ uint64_t sKeys[];
-  __shared__ int scratch[BOW_THREADS];
+  __shared__ int scratch[BOWA_THREADS];
   __shared__ int sM;
   __shared__ double sNorm;
   const int f = blockIdx.x, tid = threadIdx.x;
   const int n = nP[f];
   const size_t fo = (size_t)f * cap;
-  uint64_t* keys = keyWs ? keyWs + (size_t)f * P : sKeys;
+  uint64_t* keys;
+  if constexpr (KEYS_GLOBAL) keys = keyWs + (size_t)f * P;
+  else keys = sKeys;
   int* runStart = fvStart + (size_t)f * (cap + 1);   // also used for the word runs, rewritten below
   // features that take part: weight > 0 ("not stopped")
   if (tid == 0) sM = 0;
   __syncthreads();
   int mine = 0;
-  for (int i = tid; i < n; i += BOW_THREADS) mine += featWeight[fo + i] > 0 ? 1 : 0;
+  for (int i = tid; i < n; i += BOWA_THREADS) mine += featWeight[fo + i] > 0 ? 1 : 0;
   atomicAdd(&sM, mine);
   __syncthreads();
   const int m = sM;
 
   // ---- BowVector -------------------------------------------------------------------------
-  for (int t = tid; t < P; t += BOW_THREADS)
+  for (int t = tid; t < P; t += BOWA_THREADS)
     keys[t] = (t < n && featWeight[fo + t] > 0) ? (((uint64_t)featWord[fo + t] << 32) | (unsigned)t)
                                                 : ~(uint64_t)0;
   __syncthreads();
   block_sort(keys, P);
   const int R = block_runs(keys, m, runStart, scratch);
-  for (int r = tid; r < R; r += BOW_THREADS) {
+  for (int r = tid; r < R; r += BOWA_THREADS) {
     const int s = runStart[r], e = runStart[r + 1];
     // BowVector::addWeight in feature order: the first occurrence stores w, the others add w
     const double w = featWeight[fo + (uint32_t)keys[s]];
@@ -162,28 +182,41 @@ __global__ __launch_bounds__(BOW_THREADS) void k_bow_assemble(const int* __restr
     bowVal[fo + r] = v;
   }
   __syncthreads();
+  // BowVector::normalize(L1): the norm is accumulated in ascending word order, by one thread.
+  // The values go through the key array (free until the second sort), eight loads in flight:
+  // read one by one from where the other threads just wrote them, this sum was half the kernel.
+  double* vals = (double*)keys;
+  for (int r = tid; r < R; r += BOWA_THREADS) vals[r] = bowVal[fo + r];
+  __syncthreads();
   if (tid == 0) {
-    // BowVector::normalize(L1): the norm is accumulated in ascending word order
     double norm = 0.0;
-    for (int r = 0; r < R; ++r) norm += fabs(bowVal[fo + r]);
+    int r = 0;
+    for (; r + 8 <= R; r += 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = vals[r + u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) norm += fabs(v[u]);
+    }
+    for (; r < R; ++r) norm += fabs(vals[r]);
     sNorm = norm;
     bowCount[f] = R;
   }
   __syncthreads();
   const double norm = sNorm;
   if (norm > 0.0)
-    for (int r = tid; r < R; r += BOW_THREADS) bowVal[fo + r] = bowVal[fo + r] / norm;
+    for (int r = tid; r < R; r += BOWA_THREADS) bowVal[fo + r] = bowVal[fo + r] / norm;
   __syncthreads();
 
   // ---- FeatureVector ---------------------------------------------------------------------
-  for (int t = tid; t < P; t += BOW_THREADS)
+  for (int t = tid; t < P; t += BOWA_THREADS)
     keys[t] = (t < n && featWeight[fo + t] > 0) ? (((uint64_t)featNode[fo + t] << 32) | (unsigned)t)
                                                 : ~(uint64_t)0;
   __syncthreads();
   block_sort(keys, P);
   const int Rn = block_runs(keys, m, runStart, scratch);
-  for (int r = tid; r < Rn; r += BOW_THREADS) fvNode[fo + r] = (uint32_t)(keys[runStart[r]] >> 32);
-  for (int t = tid; t < m; t += BOW_THREADS) fvFeat[fo + t] = (uint32_t)keys[t];
+  for (int r = tid; r < Rn; r += BOWA_THREADS) fvNode[fo + r] = (uint32_t)(keys[runStart[r]] >> 32);
+  for (int t = tid; t < m; t += BOWA_THREADS) fvFeat[fo + t] = (uint32_t)keys[t];
   if (tid == 0) fvCount[f] = Rn;
 }
 
@@ -195,9 +228,14 @@ void launch_bow(const VocDevice& voc, const uint8_t* d_desc, const int* d_n, int
   hipLaunchKernelGGL(k_bow_descend, dim3((cap + perBlock - 1) / perBlock, nframes), dim3(BOW_THREADS), 0, s, voc,
                      (const uint32_t*)d_desc, d_n, cap, voc.L - levelsup, b.featWord, b.featWeight, b.featNode);
   const size_t lds = b.keyWs ? 0 : bow_keys_lds_bytes(b.P);
-  hipLaunchKernelGGL(k_bow_assemble, dim3(nframes), dim3(BOW_THREADS), lds, s, d_n, cap, b.P, b.featWord,
-                     b.featWeight, b.featNode, b.keyWs, b.bowWord, b.bowVal, b.bowCount, b.fvNode, b.fvStart,
-                     b.fvFeat, b.fvCount);
+  if (b.keyWs)
+    hipLaunchKernelGGL(k_bow_assemble<true>, dim3(nframes), dim3(BOWA_THREADS), lds, s, d_n, cap, b.P, b.featWord,
+                       b.featWeight, b.featNode, b.keyWs, b.bowWord, b.bowVal, b.bowCount, b.fvNode, b.fvStart,
+                       b.fvFeat, b.fvCount);
+  else
+    hipLaunchKernelGGL(k_bow_assemble<false>, dim3(nframes), dim3(BOWA_THREADS), lds, s, d_n, cap, b.P, b.featWord,
+                       b.featWeight, b.featNode, b.keyWs, b.bowWord, b.bowVal, b.bowCount, b.fvNode, b.fvStart,
+                       b.fvFeat, b.fvCount);
 }
 
 }  // namespace orbx

@@ -59,3 +59,23 @@ pm = np.stack([ka["x"], ka["y"]], 1).astype(np.float32)
 r = guided.search_for_initialization(exb, 0, ka, da, pm, 100, 0.9, True)
 print("SearchForInitialization: %d matches in %d rounds" % (r[0], r[3]))
 print("SearchForInitialization:                  %.3f ms" % med(lambda: guided.search_for_initialization(exb, 0, ka, da, pm, 100, 0.9, True)))
+# ComputeBoW of the frame and SearchByBoW against a keyframe (TrackReferenceKeyFrame): a synthetic
+# tree with k = 10, L = 5 and the feature vector two levels below the root (100 nodes, as ORBvoc.txt's
+# k = 10, L = 6 with levelsup = 4 gives)
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import voc_util
+from orb_slam3_amd import bow
+arrays = voc_util.make_vocabulary(10, 5, seed=3)
+voc = bow.ORBVocabulary.from_arrays(10, 5, *arrays)
+exa2 = orbx.ORBextractor(1000, 1.2, 8, 20, 7)
+exa2(a, None, (0, 0)); bow.transform_batch(exa2, voc, 1, 3)
+kf = bow.download(exa2, 0)
+print("ComputeBoW (orbx_bow_transform_batch_device + download): %.3f ms" % med(
+    lambda: (bow.transform_batch(exb, voc, 1, 3), bow.download(exb, 0))))
+valid1 = np.ones(len(ka), np.uint8)
+print("bow.download returns:", [type(x).__name__ + str(getattr(x, "shape", "")) for x in kf])
+_, _, kn, ks, kfeat = kf
+r = guided.search_by_bow(exb, 0, valid1, ka["angle"], da, kn, ks, kfeat, 0.7, True)
+print("SearchByBoW: %d matches" % r[0])
+print("SearchByBoW:                              %.3f ms" % med(
+    lambda: guided.search_by_bow(exb, 0, valid1, ka["angle"], da, kn, ks, kfeat, 0.7, True)))
