@@ -2552,9 +2552,12 @@ int orbx_search_by_bow(orbx_extractor* f, int frame, int n_kf, const uint8_t* kf
   if (const int js_ = ex->joinParts()) return js_;
   auto& last_hip_error = ex->last_hip_error;
   hipStream_t s = ex->stream;
+  GuidedCall call{ex, s};
   int n = 0;
-  HIP_TRY(hipMemcpyAsync(&n, ex->d_n + frame, 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
+  {
+    const int st = call.count(frame, &n);
+    if (st != ORBX_OK) return st;
+  }
   if (n_out) *n_out = n;
   *nmatches = 0;
   if (n > cap) return ORBX_ERR_CAPACITY;
@@ -2565,17 +2568,17 @@ int orbx_search_by_bow(orbx_extractor* f, int frame, int n_kf, const uint8_t* kf
   Carver c;
   const size_t oValid = c.add(nk), oAng = c.add(nk * 4), oDesc = c.add(nk * 32), oNode = c.add(nn * 4),
                oStart = c.add((nn + 1) * 4), oFeat = c.add(nf * 4), oM = c.add((size_t)kc * 4), oSum = c.add(8);
-  uint8_t* d = nullptr;
-  hipError_t e = hipMallocAsync((void**)&d, c.total, s);
-  if (e != hipSuccess) { last_hip_error = e; return ORBX_ERR_HIP; }
-  PackedUpload pk;
-  if (!pk.init(oM)) { (void)hipFreeAsync(d, s); return ORBX_ERR_UNSUPPORTED; }
-  auto up = [&](size_t off, const void* src, size_t bytes) { pk.add(off, src, bytes); };
+  {
+    const int st = call.begin(c.total, oM);
+    if (st != ORBX_OK) return st;
+  }
+  uint8_t* d = call.d;
+  auto up = [&](size_t off, const void* src, size_t bytes) { call.add(off, src, bytes); };
   up(oValid, kf_valid, (size_t)n_kf); up(oAng, kf_angle, (size_t)n_kf * 4); up(oDesc, kf_desc, (size_t)n_kf * 32);
   up(oNode, kf_node_ids, (size_t)n_kf_nodes * 4);
   if (n_kf_nodes > 0) up(oStart, kf_node_start, ((size_t)n_kf_nodes + 1) * 4);
   up(oFeat, kf_features, (size_t)nFeat * 4);
-  e = pk.send(d, s);
+  hipError_t e = call.send();
   int sum[2] = {0, 0};
   if (e == hipSuccess) {
     const size_t base = (size_t)frame * kc;
@@ -2587,13 +2590,7 @@ int orbx_search_by_bow(orbx_extractor* f, int frame, int n_kf, const uint8_t* kf
                                check_orientation != 0, (int*)(d + oM), (int*)(d + oSum), s);
     e = hipGetLastError();
   }
-  if (e == hipSuccess) e = hipMemcpyAsync(matches, d + oM, (size_t)n * 4, hipMemcpyDeviceToHost, s);
-  if (e == hipSuccess) e = hipMemcpyAsync(sum, d + oSum, 4, hipMemcpyDeviceToHost, s);
-  {   // also after an error: the packed host block must outlive whatever was enqueued
-    const hipError_t es = hipStreamSynchronize(s);
-    if (e == hipSuccess) e = es;
-  }
-  (void)hipFreeAsync(d, s);
+  e = call.finish(e, oM, (size_t)n, oSum, matches, sum);
   if (e != hipSuccess) { last_hip_error = e; return ORBX_ERR_HIP; }
   *nmatches = sum[0];
   return ORBX_OK;
