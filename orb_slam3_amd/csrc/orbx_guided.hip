@@ -256,7 +256,7 @@ struct ProjectionArgs {
 // choice of last-frame keypoint i given the closing times of the previous round
 // (matcher.cc:1607-1690): the keypoint it matches, or -1.  store: remember the candidates.
 // decide = false only walks and stores (closedAt is not read).
-__device__ int projection_choice(const ProjectionArgs& a, int i, const int* closedAt, bool store, bool decide = true) {
+__device__ __forceinline__ int projection_choice(const ProjectionArgs& a, int i, const int* closedAt, bool store, bool decide = true) {
   if (store) a.candCount[i] = 0;
   if (!a.lastValid[i]) return -1;
   if (a.gate && a.gate[i] == 0) return -1;
@@ -301,7 +301,7 @@ __device__ int projection_choice(const ProjectionArgs& a, int i, const int* clos
 }
 
 // the same decision from the remembered candidates (same order, so the same ties)
-__device__ int projection_choice_cached(const ProjectionArgs& a, int i, const int* closedAt, int cnt) {
+__device__ __forceinline__ int projection_choice_cached(const ProjectionArgs& a, int i, const int* closedAt, int cnt) {
   int bestDist = 256, bestIdx2 = -1;
   for (int k = 0; k < cnt; ++k) {
     const uint32_t e = a.cand[(size_t)k * a.nLast + i];
@@ -350,24 +350,28 @@ __global__ __launch_bounds__(GATHER_THREADS) void k_gather_projection(Projection
       &a.candCount[i], colS[w], colP[w]);
 }
 
-__global__ __launch_bounds__(GUIDED_THREADS) void k_search_by_projection_last(ProjectionArgs a) {
-  __shared__ int hist[HISTO_LENGTH];
-  __shared__ int keep[3];
-  __shared__ int nmS;
+// The rounds of the last-frame matcher with the two generations of choices and closing times
+// where the caller puts them.  Inlined once with LDS arrays (a usual frame) and once with the
+// caller's work memory, so that in the first every access of a round is an LDS instruction:
+// the arrays are read and rewritten by all threads in every round, and in global memory every one
+// of those is a trip to the L2, where its atomics execute.
+#define ROUNDS_LDS_MAX 2048   /* queries and keypoints per LDS array */
+__device__ __forceinline__ void projection_rounds(const ProjectionArgs& a, int* choice0, int* choice1, int* closed0,
+                                                  int* closed1, int* hist, int* keep, int* nmS) {
   const int tid = threadIdx.x;
   const int OPEN = 0x7fffffff;
-  for (int i = tid; i < a.nLast; i += GUIDED_THREADS) a.choice[0][i] = -1;
+  for (int i = tid; i < a.nLast; i += GUIDED_THREADS) choice0[i] = -1;
   for (int i2 = tid; i2 < a.n; i2 += GUIDED_THREADS)
-    a.closedAt[0][i2] = (a.state && a.state[i2] == 1) ? -1 : OPEN;
+    closed0[i2] = (a.state && a.state[i2] == 1) ? -1 : OPEN;
   if (tid < HISTO_LENGTH) hist[tid] = 0;
-  if (tid == 0) nmS = 0;
+  if (tid == 0) *nmS = 0;
   __syncthreads();
   int cur = 0, rounds = 0;
   for (;;) {
-    const int* cPrev = a.choice[cur];
-    int* cNew = a.choice[cur ^ 1];
-    const int* bPrev = a.closedAt[cur];
-    int* bNew = a.closedAt[cur ^ 1];
+    const int* cPrev = cur ? choice1 : choice0;
+    int* cNew = cur ? choice0 : choice1;
+    const int* bPrev = cur ? closed1 : closed0;
+    int* bNew = cur ? closed0 : closed1;
     int changed = 0;
     for (int i = tid; i < a.nLast; i += GUIDED_THREADS) {
       int c;
@@ -394,14 +398,14 @@ __global__ __launch_bounds__(GUIDED_THREADS) void k_search_by_projection_last(Pr
     if (!any || rounds > a.nLast + 1) break;
   }
   // matcher.cc:1682-1700: the last query that took a keypoint keeps it; every take counts
-  const int* choice = a.choice[cur];
+  const int* choice = cur ? choice1 : choice0;
   for (int i2 = tid; i2 < a.n; i2 += GUIDED_THREADS) a.assigned[i2] = -1;
   __syncthreads();
   for (int i = tid; i < a.nLast; i += GUIDED_THREADS) {
     const int c = choice[i];
     if (c >= 0) {
       atomicMax(&a.assigned[c], i);
-      atomicAdd(&nmS, 1);
+      atomicAdd(nmS, 1);
       if (a.checkOrientation && !a.deferRotation) {
         const int bin = rotation_bin(a.lastAngle[i], a.grid.U[c].angle);
         if (bin >= 0 && bin < HISTO_LENGTH) atomicAdd(&hist[bin], 1);
@@ -420,13 +424,24 @@ __global__ __launch_bounds__(GUIDED_THREADS) void k_search_by_projection_last(Pr
         const int bin = rotation_bin(a.lastAngle[i], a.grid.U[c].angle);
         if (bin >= 0 && bin < HISTO_LENGTH && bin != keep[0] && bin != keep[1] && bin != keep[2]) {
           a.assigned[c] = -2;
-          atomicSub(&nmS, 1);
+          atomicSub(nmS, 1);
         }
       }
     }
     __syncthreads();
   }
-  if (tid == 0) { a.summary[0] = nmS; a.summary[1] = rounds; }
+  if (tid == 0) { a.summary[0] = *nmS; a.summary[1] = rounds; }
+}
+
+__global__ __launch_bounds__(GUIDED_THREADS) void k_search_by_projection_last(ProjectionArgs a) {
+  __shared__ int hist[HISTO_LENGTH];
+  __shared__ int keep[3];
+  __shared__ int nmS;
+  __shared__ int gen[4 * ROUNDS_LDS_MAX];
+  if (a.nLast <= ROUNDS_LDS_MAX && a.n <= ROUNDS_LDS_MAX)
+    projection_rounds(a, gen, gen + ROUNDS_LDS_MAX, gen + 2 * ROUNDS_LDS_MAX, gen + 3 * ROUNDS_LDS_MAX, hist, keep, &nmS);
+  else
+    projection_rounds(a, a.choice[0], a.choice[1], a.closedAt[0], a.closedAt[1], hist, keep, &nmS);
 }
 
 // The rotation check of matcher.cc:1788-1805 over the matches of both cameras of a rig: one
@@ -606,11 +621,11 @@ __device__ __forceinline__ BestTwo points_walk_cached(const PointsArgs& a, int i
 }
 
 // choice of map point i given the closing times of the previous round
-__device__ int points_choice(const PointsArgs& a, int i, const int* closedAt, bool store, bool decide = true) {
+__device__ __forceinline__ int points_choice(const PointsArgs& a, int i, const int* closedAt, bool store, bool decide = true) {
   return points_walk(a, i, [&](int i2) { return coherent_load(&closedAt[i2]) < i; }, store, decide).accepted(a.nnratio);
 }
 
-__device__ int points_choice_cached(const PointsArgs& a, int i, const int* closedAt, int cnt) {
+__device__ __forceinline__ int points_choice_cached(const PointsArgs& a, int i, const int* closedAt, int cnt) {
   return points_walk_cached(a, i, [&](int i2) { return coherent_load(&closedAt[i2]) < i; }, cnt).accepted(a.nnratio);
 }
 
@@ -641,21 +656,21 @@ __global__ __launch_bounds__(GATHER_THREADS) void k_gather_points(PointsArgs a) 
       a.cand, (size_t)a.nPts, i, &a.candCount[i], colS[w], colP[w]);
 }
 
-__global__ __launch_bounds__(GUIDED_THREADS) void k_search_by_projection_points(PointsArgs a) {
-  __shared__ int nmS;
+__device__ __forceinline__ void points_rounds(const PointsArgs& a, int* choice0, int* choice1, int* closed0,
+                                              int* closed1, int* nmS) {
   const int tid = threadIdx.x;
   const int OPEN = 0x7fffffff;
-  for (int i = tid; i < a.nPts; i += GUIDED_THREADS) a.choice[0][i] = -1;
+  for (int i = tid; i < a.nPts; i += GUIDED_THREADS) choice0[i] = -1;
   for (int i2 = tid; i2 < a.n; i2 += GUIDED_THREADS)
-    a.closedAt[0][i2] = (a.state && a.state[i2] == 1) ? -1 : OPEN;
-  if (tid == 0) nmS = 0;
+    closed0[i2] = (a.state && a.state[i2] == 1) ? -1 : OPEN;
+  if (tid == 0) *nmS = 0;
   __syncthreads();
   int cur = 0, rounds = 0;
   for (;;) {
-    const int* cPrev = a.choice[cur];
-    int* cNew = a.choice[cur ^ 1];
-    const int* bPrev = a.closedAt[cur];
-    int* bNew = a.closedAt[cur ^ 1];
+    const int* cPrev = cur ? choice1 : choice0;
+    int* cNew = cur ? choice0 : choice1;
+    const int* bPrev = cur ? closed1 : closed0;
+    int* bNew = cur ? closed0 : closed1;
     int changed = 0;
     for (int i = tid; i < a.nPts; i += GUIDED_THREADS) {
       int c;
@@ -681,18 +696,28 @@ __global__ __launch_bounds__(GUIDED_THREADS) void k_search_by_projection_points(
     if (!any || rounds > a.nPts + 1) break;
   }
   // matcher.cc:127-138: the last map point that took a keypoint keeps it; every take counts
-  const int* choice = a.choice[cur];
+  const int* choice = cur ? choice1 : choice0;
   for (int i2 = tid; i2 < a.n; i2 += GUIDED_THREADS) a.assigned[i2] = -1;
   __syncthreads();
   for (int i = tid; i < a.nPts; i += GUIDED_THREADS) {
     const int c = choice[i];
     if (c >= 0) {
       atomicMax(&a.assigned[c], i);
-      atomicAdd(&nmS, 1);
+      atomicAdd(nmS, 1);
     }
   }
   __syncthreads();
-  if (tid == 0) { a.summary[0] = nmS; a.summary[1] = rounds; }
+  if (tid == 0) { a.summary[0] = *nmS; a.summary[1] = rounds; }
+}
+
+__global__ __launch_bounds__(GUIDED_THREADS) void k_search_by_projection_points(PointsArgs a) {
+  __shared__ int nmS;
+  __shared__ int gen[4 * ROUNDS_LDS_MAX];
+  // (as in k_search_by_projection_last: the generations in LDS when the frame is of usual size)
+  if (a.nPts <= ROUNDS_LDS_MAX && a.n <= ROUNDS_LDS_MAX)
+    points_rounds(a, gen, gen + ROUNDS_LDS_MAX, gen + 2 * ROUNDS_LDS_MAX, gen + 3 * ROUNDS_LDS_MAX, &nmS);
+  else
+    points_rounds(a, a.choice[0], a.choice[1], a.closedAt[0], a.closedAt[1], &nmS);
 }
 
 // ORBmatcher::SearchByProjection(F, vpMapPoints, th) for a frame with two cameras (F.Nleft != -1,
