@@ -372,6 +372,74 @@ def stereo_bench(torch, orbx, dev, local_rank, batch=128, reps=5):
     return res
 
 
+def tracking_calls_bench(orbx, local_rank, reps=200):
+    """Blocking latency (median per call, ms) of the calls a tracking thread makes per frame, on
+    752x480 frames with 1000 keypoints: a stereo pair through orbx_extract_batch, the association of
+    Frame::ComputeStereoMatches, the frame grid, SearchByProjection(CurrentFrame, LastFrame) and
+    SearchByProjection(F, map points) (core/lib/ORB/matcher.cc:1591-1808, 41-142)."""
+    import ctypes as C
+    import numpy as np
+    from orb_slam3_amd import grid, guided, matcher
+    from orb_slam3_amd._lib import lib, check
+    shift = 6
+    wide = orbx.textured_frame(41, W + shift, H)
+    a = np.ascontiguousarray(wide[:, shift:])
+    b = np.ascontiguousarray(wide[:, :W])
+    exa = orbx.ORBextractor(*PARAMS, device=local_rank)
+    exb = orbx.ORBextractor(*PARAMS, device=local_rank)
+    _, ka, da = exa(a, None, (0, 0))
+    _, kb, db = exb(b, None, (0, 0))
+    bounds = grid.image_bounds(None, W, H)
+    rng = np.random.default_rng(5)
+    nl = len(ka)
+    uv = np.stack([ka["x"] + shift + rng.uniform(-2, 2, nl), ka["y"] + rng.uniform(-2, 2, nl)], 1).astype(np.float32)
+    invz = rng.uniform(0.05, 1.0, nl).astype(np.float32)
+    ones = np.ones(nl, np.uint8)
+    state = np.zeros(len(kb), np.uint8)
+
+    def med(fn):
+        for _ in range(20):
+            fn()
+        per = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            per.append(time.perf_counter() - t0)
+        return float(np.median(per)) * 1e3
+
+    out = {"unit": "ms per blocking call, median of %d" % reps, "keypoints": int(len(kb))}
+    pair = orbx.ORBextractor(*PARAMS, device=local_rank, max_batch=2)
+    cap = pair.max_keypoints()
+    two = np.stack([a, b])
+    ptrs = (C.c_void_p * 2)(two[0].ctypes.data, two[1].ctypes.data)
+    k2 = np.zeros((2, cap * 28), np.uint8)
+    d2 = np.zeros((2, cap * 32), np.uint8)
+    n2 = np.zeros(2, np.int32)
+    m2 = np.zeros(2, np.int32)
+    i32p = C.POINTER(C.c_int32)
+    out["extract_pair"] = med(lambda: check(lib().orbx_extract_batch(
+        pair._h, 2, ptrs, W, H, W, 0, 0, k2.ctypes.data_as(C.c_void_p), d2.ctypes.data_as(C.c_void_p), cap,
+        n2.ctypes.data_as(i32p), m2.ctypes.data_as(i32p)), "orbx_extract_batch"))
+    out["stereo_match"] = med(lambda: matcher.compute_stereo_matches(exb, exa, 47.9, 0.11))
+    out["frame_grid"] = med(lambda: (grid.frame_grid_batch(exb, 1, None, bounds), exb.sync()))
+    grid.frame_grid_batch(exb, 1, None, bounds)
+    sbp = lambda: guided.search_by_projection_last(exb, 0, ones, uv, invz, ka["octave"], ka["angle"], da, ones, None,
+                                                   state, 15.0, 0, 0, 40.0, True)
+    out["search_by_projection_last"] = med(sbp)
+    out["search_by_projection_last_matches"] = int((sbp()[1] >= 0).sum())
+    npts = 2 * nl
+    proj = np.concatenate([uv, uv + 0.7]).astype(np.float32)
+    lvl = np.concatenate([ka["octave"], ka["octave"]])
+    dd = np.concatenate([da, da])
+    pts = lambda: guided.search_by_projection_points(exb, 0, np.ones(npts, np.uint8), proj, np.full(npts, -1, np.float32),
+                                                     lvl, np.full(npts, 0.999, np.float32), dd, np.ones(npts, np.uint8),
+                                                     None, state, 1.0, 0.8)
+    out["search_by_projection_points_%d" % npts] = med(pts)
+    for e in (exa, exb, pair):
+        e.close()
+    return out
+
+
 def fisheye_bench(torch, orbx, dev, local_rank, batch=128, reps=5):
     """Secondary metric: fisheye stereo pairs/s (config: 512x512 pair, 1500 kp per camera, lapping
     areas): both extractions for the whole batch, then per pair the brute-force 2-NN of the left
@@ -826,7 +894,8 @@ def main():
                      ("fisheye", lambda: fisheye_bench(torch, orbx, dev, local_rank)),
                      ("kitti", lambda: kitti_bench(torch, orbx, dev, local_rank)),
                      ("kitti_stereo", lambda: kitti_stereo_bench(torch, orbx, dev, local_rank)),
-                     ("uhd", lambda: uhd_bench(torch, orbx, dev, local_rank))]
+                     ("uhd", lambda: uhd_bench(torch, orbx, dev, local_rank)),
+                     ("tracking_calls", lambda: tracking_calls_bench(orbx, local_rank))]
         elif args.stereo:
             legs.append(("stereo", lambda: stereo_bench(torch, orbx, dev, local_rank)))
         if args.bow:
