@@ -398,7 +398,10 @@ __device__ __forceinline__ void knn2_fp4_scan(const uint32_t* __restrict__ q, in
     for (int s = 0; s < 8; ++s) pc += __builtin_popcount(w[s]);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const km_v4i e = bits_to_fp4(h ? w[2 * s + 1] : w[2 * s]);
+      // (the half's word by mask: a select between two elements of w[] by a run-time condition
+      // becomes an indexed read of the array in scratch memory)
+      const uint32_t hm = 0u - (uint32_t)h;
+      const km_v4i e = bits_to_fp4((w[2 * s + 1] & hm) | (w[2 * s] & ~hm));
       bq[qt][s].x = fp4_pm1(e.x); bq[qt][s].y = fp4_pm1(e.y); bq[qt][s].z = fp4_pm1(e.z); bq[qt][s].w = fp4_pm1(e.w);
     }
     qpop[qt] = (float)pc;
