@@ -124,3 +124,36 @@ def test_header_is_plain_c():
     """The boundary is a C ABI: include/orbx.h compiles as C99 with warnings as errors."""
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c",
                            os.path.join(ROOT, "include", "orbx.h")])
+
+
+def test_no_kernel_of_the_built_library_uses_scratch_memory(tmp_path):
+    """Every kernel of liborbx_hip.so keeps its state in registers and LDS: the code objects'
+    metadata must give a private segment of 0 bytes per lane for each of them (a run-time index
+    into a local array, or a register spill, would show up here as scratch memory)."""
+    import re
+    import shutil
+    llvm = "/opt/rocm/lib/llvm/bin"
+    so = os.path.join(ROOT, "orb_slam3_amd", "liborbx_hip.so")
+    if not (os.path.exists(so) and os.path.exists(os.path.join(llvm, "llvm-objdump"))):
+        pytest.skip("built library or LLVM tools not present")
+    shutil.copy(so, tmp_path / "lib.so")
+    subprocess.check_call([os.path.join(llvm, "llvm-objdump"), "--offloading", "lib.so"], cwd=tmp_path,
+                          stdout=subprocess.DEVNULL)
+    objs = sorted(p for p in os.listdir(tmp_path) if "amdgcn" in p)
+    assert objs, "no device code object found in the library"
+    kernels = {}
+    for o in objs:
+        assert o.endswith("gfx950"), o
+        notes = subprocess.check_output([os.path.join(llvm, "llvm-readelf"), "--notes", o], cwd=tmp_path, text=True)
+        name = None
+        for line in notes.splitlines():
+            m = re.search(r"\.name:\s+(\S+)", line)
+            if m:
+                name = m.group(1)
+            m = re.search(r"\.private_segment_fixed_size:\s+(\d+)", line)
+            if m and name:
+                kernels[name] = int(m.group(1))
+    assert len(kernels) >= 40, sorted(kernels)
+    assert any("k_knn2_fp4" in k for k in kernels) and any("k_fast_cells" in k for k in kernels)
+    with_scratch = {k: v for k, v in kernels.items() if v != 0}
+    assert not with_scratch, with_scratch
