@@ -32,9 +32,12 @@ def test_gpu_suite_under_host_simulation(guard, order, lib):
     env = dict(os.environ, ORBX_HOSTSIM="1", HOSTSIM_GUARD=guard, HOSTSIM_ORDER=order, ORBX_HOSTSIM_LIB=lib)
     cmd = [sys.executable, "-m", "pytest", os.path.join(ROOT, "tests"), "-m", "gpu", "-q", "-x",
            "-p", "no:faulthandler", "-p", "no:cacheprovider"]
-    if (guard, order) != ("end", "forward"):
-        # the large-batch schedule cases run in full in the first variant; one of each kind here
-        cmd += ["-k", "not schedule_knobs or PARTS-3 or FAST_QCAP"]
+    if (guard, order) == ("end", "forward"):
+        # every schedule knob once, with the parts joined at the end of the call (the pipelined half
+        # of that matrix runs on the GPU and, one case of each kind, in the other two variants)
+        cmd += ["-k", "not schedule_knobs or False-ORBX"]
+    else:
+        cmd += ["-k", "not schedule_knobs or True-ORBX_PARTS-3 or True-ORBX_FAST_QCAP"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     tail = (out.stdout + out.stderr)[-3000:]
     assert out.returncode == 0, tail
