@@ -545,6 +545,16 @@ __device__ __forceinline__ void fast_cut_tile(const uint8_t* tile, uint8_t* q6, 
   }
 }
 
+// Is m (= q[0]) above its eight neighbours in the map of m?  All eight are loaded before the
+// compare: written as a chain of && the test became eight dependent LDS round trips with a branch
+// each (detection alone 0.886 -> 0.855 ms per 1024 frames).
+template <int TS>
+__device__ __forceinline__ bool nms_is_max(const uint8_t* q, int m) {
+  const int n0 = q[-1], n1 = q[1], n2 = q[-TS - 1], n3 = q[-TS], n4 = q[-TS + 1], n5 = q[TS - 1], n6 = q[TS],
+            n7 = q[TS + 1];
+  return m > max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
+}
+
 // What a detection pass leaves behind for the output step.
 struct FastPass {
   bool anyHi;      // some suppressed corner has m > thHi
@@ -635,8 +645,7 @@ __device__ __forceinline__ FastPass fast_pass(const uint8_t* tile, const uint8_t
       const uint8_t* q = mm + (y + 1) * TS + x + 4;
       const int m = q[0];
       if (m > tlow) {
-        const bool isMax = m > q[-1] && m > q[1] && m > q[-TS - 1] && m > q[-TS] && m > q[-TS + 1] &&
-                           m > q[TS - 1] && m > q[TS] && m > q[TS + 1];
+        const bool isMax = nms_is_max<TS>(q, m);
         if (isMax) {
           if (m > thHi) { atomicOr(&bitsHi[qi >> 5], 1u << (qi & 31)); anyHi = 1; }
           if (bitsLo && m > thLo) atomicOr(&bitsLo[qi >> 5], 1u << (qi & 31));
@@ -672,8 +681,7 @@ __device__ __forceinline__ FastPass fast_pass(const uint8_t* tile, const uint8_t
         const int id = queue[qi], x = id & 127, y = id >> 7;
         const uint8_t* q = mm + (y + 1) * TS + x + 4;
         const int m = q[0];
-        const bool isMax = m > q[-1] && m > q[1] && m > q[-TS - 1] && m > q[-TS] && m > q[-TS + 1] &&
-                           m > q[TS - 1] && m > q[TS] && m > q[TS + 1];
+        const bool isMax = nms_is_max<TS>(q, m);
         if (isMax) {
           const int p = y * cw + x;
           if (m > thHi) { atomicOr(&bitsHi[p >> 5], 1u << (p & 31)); anyHi = 1; }
