@@ -579,29 +579,38 @@ __device__ __forceinline__ FastPass fast_pass(const uint8_t* tile, const uint8_t
   wave_sync();
   // ---- 2. quick rejection, 4 columns x 2 rows per lane ----------------------
   // Survivors are queued as (task row << 10 | task column << 5 | flag bit): bits 3..9 of an entry
-  // are the pixel's column, bit 2 its row inside the task, bit 0 the side (0 dark, 1 bright); a
-  // pixel that can be either is queued twice.  The position comes from an LDS counter, so the
+  // are the pixel's column, bit 2 its row inside the task, bit 1 says that the task lies one trip
+  // (rpt task rows) below the entry's task row, bit 0 is the side (0 dark, 1 bright); a pixel that
+  // can be either is queued twice.  The position comes from an LDS counter, so the
   // order of the queue is arbitrary - nothing below depends on it.
   if (c6 >= 1) {
     const uint32_t k = (0x7fu + c6) * 0x01010101u;
     const bool laneOn = lr < rpt;
     const uint8_t* wp = q6 + (2 * lr) * TS + 4 * gx;
     uint32_t base = ((uint32_t)lr << 10) | ((uint32_t)gx << 5);
-    for (int r0 = 0; r0 < nry; r0 += rpt) {
-      if (laneOn && r0 + lr < nry) {
-        uint32_t R[8][3];
+    // Two trips of the task grid per turn: the flags of the second go into the free bits of the
+    // first's word (shifted up by two), so that a pair of trips costs one trip through the LDS
+    // counter and one append loop, and the window rows of both are requested together.
+    auto flags = [&](const uint8_t* p) -> uint32_t {
+      uint32_t R[8][3];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const uint32_t* rp = (const uint32_t*)(wp + i * TS);
-          R[i][0] = rp[0]; R[i][1] = rp[1]; R[i][2] = rp[2];
-        }
-        uint32_t d0, b0, d1, b1;
-        quick4<3>(R, k, d0, b0);   // upper row of the task
-        quick4<4>(R, k, d1, b1);   // lower row
-        // dark flags in bits 0, 8, 16, 24 (upper row) and 4, 12, 20, 28 (lower row), bright flags
-        // one bit above them.  Pixels of the last column group / row that lie outside the cell
-        // are not masked here: the consumers of the queue skip them.
-        uint32_t F = (d0 >> 7) | (d1 >> 3) | (b0 >> 6) | (b1 >> 2);
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t* rp = (const uint32_t*)(p + i * TS);
+        R[i][0] = rp[0]; R[i][1] = rp[1]; R[i][2] = rp[2];
+      }
+      uint32_t d0, b0, d1, b1;
+      quick4<3>(R, k, d0, b0);   // upper row of the task
+      quick4<4>(R, k, d1, b1);   // lower row
+      // dark flags in bits 0, 8, 16, 24 (upper row) and 4, 12, 20, 28 (lower row), bright flags
+      // one bit above them.  Pixels of the last column group / row that lie outside the cell
+      // are not masked here: the consumers of the queue skip them.
+      return (d0 >> 7) | (d1 >> 3) | (b0 >> 6) | (b1 >> 2);
+    };
+    const int step = 2 * rpt * TS;
+    for (int r0 = 0; r0 < nry; r0 += 2 * rpt) {
+      if (laneOn && r0 + lr < nry) {
+        uint32_t F = flags(wp);
+        if (r0 + rpt + lr < nry) F |= flags(wp + step) << 2;
         if (F) {
           const int n = __popc(F);
           const int at = atomicAdd(qcnt, n);
@@ -615,8 +624,8 @@ __device__ __forceinline__ FastPass fast_pass(const uint8_t* tile, const uint8_t
           }
         }
       }
-      wp += 2 * rpt * TS;
-      base += (uint32_t)rpt << 10;
+      wp += 2 * step;
+      base += (uint32_t)(2 * rpt) << 10;
     }
   }
   wave_sync();
@@ -661,7 +670,8 @@ __device__ __forceinline__ FastPass fast_pass(const uint8_t* tile, const uint8_t
       const int qi = q0 + lane;
       const bool have = qi < nq;
       const uint32_t e = have ? (uint32_t)queue[qi] : 0u;
-      const int x = (int)((e >> 3) & 127u), y = (int)(((e >> 10) << 1) | ((e >> 2) & 1u));
+      const int x = (int)((e >> 3) & 127u),
+                y = (int)(((e >> 10) << 1) | ((e >> 2) & 1u)) + ((e & 2u) ? 2 * rpt : 0);
       int m = 0;
       if (have && x < cw && y < ch) m = fast_m_sel<TS>(tile + (y + 3) * TS + x + 4, (e & 1u) ? 0 : 0xff);
       const bool corner = m > tlow;
